@@ -1,0 +1,221 @@
+/*
+ * sppm_abi.h — C-ABI of the MI355X SPPM hot path (libsppm_hip.so).
+ *
+ * The reference renderer (wondergo2017/raytrace3) has no FFI: everything is
+ * inlined C++ in one translation unit.  This header is the lower boundary that
+ * the drop-in C++ classes in include/raytrace3/ (RayTracer, SPPMRayTracer) call
+ * instead of running the reference's CPU loops.  Every entry point names the
+ * reference code it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, caller-owned host buffers.
+ *   - every call returns 0 on success, <0 on error (SPPM_E_*); the message is
+ *     available from sppm_last_error(ctx) and is owned by the context.
+ *   - a context is bound to ONE GPU and must be used from one host thread at a
+ *     time.  Multi-GPU = one context per GPU (one process per GPU under
+ *     torch.distributed / RCCL, or one context per device in a C++ host).
+ *   - geometry crosses the boundary as double (the reference's type); colours
+ *     and material coefficients as double too.  The library converts to its
+ *     device types (fp64 ray state / analytic hits / gather positions, fp32
+ *     Newton core, colours, flux and accumulators).
+ *   - no exceptions cross the boundary.
+ */
+#ifndef SPPM_ABI_H
+#define SPPM_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPPM_OK 0
+#define SPPM_E_INVALID (-1)   /* bad argument / call order */
+#define SPPM_E_DEVICE (-2)    /* HIP runtime error */
+#define SPPM_E_CAPACITY (-3)  /* an internal queue or a caller buffer is too small */
+#define SPPM_E_NOMEM (-4)
+
+/* Object kinds: raytracer/Obj.h:55 (PlaneObj), :102 (SphereObj), raytracer/Bezier.h:188 (Bezier3Obj). */
+#define SPPM_OBJ_PLANE 0
+#define SPPM_OBJ_SPHERE 1
+#define SPPM_OBJ_BEZIER 2
+
+/* raytracer/Element.h:7-19 (Material).  refln is carried for completeness; the
+ * reference never reads it on the hot path. */
+typedef struct sppm_material {
+    double diff[3];
+    double refl[3];
+    double refr[3];
+    double refrn;
+    double refln;
+} sppm_material;
+
+/* One entry of Scene::objvec (raytracer/Scene.h:96), flattened.
+ *   plane : p0 = PlaneObj::P0, n = PlaneObj::norm (already normalised, Obj.h:60-62)
+ *   sphere: p0 = SphereObj::org, radius
+ *   bezier: first_patch/n_patches index sppm_scene::patches
+ * texture = index into sppm_scene::textures or -1 (Obj::texture, Obj.h:9,50). */
+typedef struct sppm_object {
+    int32_t type;
+    int32_t texture;
+    double color[3];
+    sppm_material material;
+    double p0[3];
+    double n[3];
+    double radius;
+    int32_t first_patch;
+    int32_t n_patches;
+} sppm_object;
+
+/* raytracer/Element.h:43-75 (Texture): rows x cols texels, 3 bytes each in the
+ * channel order of the reference's m_map (OpenCV BGR), value = byte / 255. */
+typedef struct sppm_texture {
+    int32_t rows;
+    int32_t cols;
+    const uint8_t* texels;
+} sppm_texture;
+
+/* raytracer/Light.h:4-17 (Light / SpotLight): isotropic point light. */
+typedef struct sppm_light {
+    double pos[3];
+    double color[3];
+} sppm_light;
+
+/* Scene::objvec + Scene::plvec (raytracer/Scene.h:96-97) flattened.
+ * patches: n_patches x 16 x 3 doubles, P[16] of Bezier3 (raytracer/Bezier.h:165)
+ * in world space (after scale / Trans / +C of Bezier.h:213-229). */
+typedef struct sppm_scene {
+    int32_t n_objects;
+    const sppm_object* objects;
+    int32_t n_patches;
+    const double* patches;
+    int32_t n_textures;
+    const sppm_texture* textures;
+    int32_t n_lights;
+    const sppm_light* lights;
+} sppm_scene;
+
+/* Camera state after Camera::lookAt (raytracer/Camera.h:32-54): pos, the scaled
+ * view vector dir (= unit * .5/tan(fov/2)), the unit image axes du, dv and the
+ * resolution.  Camera::emit (Camera.h:18-22) is evaluated on the device. */
+typedef struct sppm_camera {
+    double pos[3];
+    double dir[3];
+    double du[3];
+    double dv[3];
+    int32_t w;
+    int32_t h;
+} sppm_camera;
+
+/* raytracer/Raytracer.h:47-80 (HitPoint) as returned for parity / debugging.
+ * x = image row, y = image column (Raytracer.h:105-111).  node is the position
+ * of the eye-path vertex in the ViewTrace recursion tree (root 0, reflection
+ * child 2n+1, refraction child 2n+2); (x, y, node) identifies a HitPoint
+ * independently of the order the device emitted it in. */
+typedef struct sppm_hitpoint {
+    double pos[3];
+    double n[3];
+    double v[3];
+    double wgt[3];
+    double tao[3];
+    double R2;
+    int32_t obj;
+    int32_t x;
+    int32_t y;
+    int32_t node;
+    int32_t N;
+    int32_t newN;
+} sppm_hitpoint;
+
+/* Work counters of everything run since sppm_eye_pass.  candidates / accepted /
+ * segments are the C / A / S of the gather byte model (40*C + 32*A + 64*S). */
+typedef struct sppm_counters {
+    uint64_t photons;        /* emitted photons */
+    uint64_t segments;       /* photon path segments traced (NearCollide calls that were kept) */
+    uint64_t deposits;       /* diffuse photon hits (radius searches in the reference) */
+    uint64_t candidates;     /* (deposit, HitPoint) pairs with dist^2 < searchR2 */
+    uint64_t accepted;       /* pairs that updated a HitPoint */
+    uint64_t hitpoints;      /* |Hvec| */
+    uint64_t newton_calls;   /* (ray, patch) Newton solves, eye + photon */
+    uint64_t eye_segments;   /* eye path segments traced */
+} sppm_counters;
+
+/* HIP-event timings (ms) of the kernels launched by the last eye / photon pass. */
+typedef struct sppm_timings {
+    double eye_trace_ms;
+    double grid_build_ms;
+    double photon_trace_ms;
+    double deposit_sort_ms;
+    double gather_ms;
+    double resolve_ms;
+    int32_t gather_launches;
+    int32_t trace_launches;
+} sppm_timings;
+
+typedef struct sppm_ctx sppm_ctx;
+
+/* Create a context on one GPU.  Fails (SPPM_E_DEVICE) if no HIP device is usable:
+ * there is no CPU fallback. */
+int sppm_create(sppm_ctx** out, int device_id);
+void sppm_destroy(sppm_ctx* ctx);
+const char* sppm_last_error(const sppm_ctx* ctx);
+
+/* Upload the flattened scene.  Replaces Scene::init's object graph as seen by
+ * Scene::NearCollide (raytracer/Scene.h:165-182); patch and object AABBs are
+ * rebuilt as Bezier3::read / Bezier3Obj do (raytracer/Bezier.h:167-175, :226-231). */
+int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* scene);
+
+/* Pass 1: RayTracer::GetHitPoint + ViewTrace (raytracer/Raytracer.h:102-116,
+ * :296-357) for every pixel, then the hash grid over HitPoints that replaces the
+ * flann kd-tree build (Raytracer.h:370-380).  Clears tao / newN and the counters. */
+int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t replica);
+
+/* Pass 2: RayTracer::PhotonMap + PhotonTrace + the radius gather
+ * (raytracer/Raytracer.h:117-209, :210-247).  The pass is rounds x n_lights x
+ * per_round photons (Raytracer.h:220-233); photon g of that sequence is traced
+ * iff photon_begin <= g < photon_begin + photon_count (photon_count 0 = all),
+ * which is how ranks shard one pass.  Accumulates into tao / newN. */
+int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round,
+                     uint64_t photon_begin, uint64_t photon_count,
+                     uint64_t seed, uint32_t replica);
+
+/* Resolve, raytracer/Raytracer.h:281-293: pic[x][y] (+)= tao / (PI * R2 * rounds * per_round)
+ * with the rounds / per_round of the last photon pass, row-major [h][w][3].
+ * accumulate = 0 overwrites pic, 1 adds to it (the image sum of Raytracer.h:449-458). */
+int sppm_resolve(sppm_ctx* ctx, double* pic_hw3, int accumulate);
+
+/* Same, into a caller-provided DEVICE buffer of h*w*3 floats (overwritten) so a
+ * collective (RCCL all-reduce of the flux image) can run on it in place. */
+int sppm_resolve_device(sppm_ctx* ctx, float* dev_pic_hw3);
+
+/* Copy out up to cap HitPoints; *n receives |Hvec|. */
+int sppm_get_hitpoints(sppm_ctx* ctx, sppm_hitpoint* out, uint64_t cap, uint64_t* n);
+int sppm_get_counters(sppm_ctx* ctx, sppm_counters* out);
+int sppm_get_timings(sppm_ctx* ctx, sppm_timings* out);
+
+/* Collision record of Scene::NearCollide for the debug entry point below
+ * (raytracer/Element.h:20-38).  obj = -1 when nothing was hit. */
+typedef struct sppm_collision {
+    double pos[3];
+    double n[3];
+    double color[3];
+    double dist;
+    int32_t obj;
+    int32_t inside;
+} sppm_collision;
+
+/* Parity hook: Scene::NearCollide (raytracer/Scene.h:165-182) for n arbitrary
+ * rays (org, dir: n x 3 doubles each).  Ray i uses the Newton random stream of
+ * (seed, replica, path = i, node = 0) of the eye pass. */
+int sppm_debug_near_collide(sppm_ctx* ctx, uint64_t n, const double* org, const double* dir,
+                            uint64_t seed, uint32_t replica, sppm_collision* out);
+
+/* Parity hook: Bezier3::newton (raytracer/Bezier.h:112-159) for n (ray, patch)
+ * pairs; out_tuv receives (t, u, v) or (1e20, 1e20, 1e20). */
+int sppm_debug_newton(sppm_ctx* ctx, uint64_t n, const double* org, const double* dir,
+                      const int32_t* patch, uint64_t seed, uint32_t replica, double* out_tuv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPPM_ABI_H */

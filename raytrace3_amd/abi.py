@@ -1,0 +1,221 @@
+"""ctypes mirror of include/sppm_abi.h and a thin wrapper over libsppm_hip.so.
+
+The structures here are the C-ABI structs field for field.  `SppmLib` loads the
+HIP library and fails loudly when it is missing or no GPU is usable: there is no
+CPU fallback in the product path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsppm_hip.so")
+
+SPPM_OBJ_PLANE, SPPM_OBJ_SPHERE, SPPM_OBJ_BEZIER = 0, 1, 2
+
+
+class Material(C.Structure):
+    _fields_ = [("diff", C.c_double * 3), ("refl", C.c_double * 3), ("refr", C.c_double * 3),
+                ("refrn", C.c_double), ("refln", C.c_double)]
+
+
+class Object(C.Structure):
+    _fields_ = [("type", C.c_int32), ("texture", C.c_int32), ("color", C.c_double * 3),
+                ("material", Material), ("p0", C.c_double * 3), ("n", C.c_double * 3),
+                ("radius", C.c_double), ("first_patch", C.c_int32), ("n_patches", C.c_int32)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("texels", C.POINTER(C.c_uint8))]
+
+
+class Light(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("color", C.c_double * 3)]
+
+
+class Scene(C.Structure):
+    _fields_ = [("n_objects", C.c_int32), ("objects", C.POINTER(Object)),
+                ("n_patches", C.c_int32), ("patches", C.POINTER(C.c_double)),
+                ("n_textures", C.c_int32), ("textures", C.POINTER(Texture)),
+                ("n_lights", C.c_int32), ("lights", C.POINTER(Light))]
+
+
+class Camera(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("dir", C.c_double * 3), ("du", C.c_double * 3),
+                ("dv", C.c_double * 3), ("w", C.c_int32), ("h", C.c_int32)]
+
+
+class HitPoint(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("n", C.c_double * 3), ("v", C.c_double * 3),
+                ("wgt", C.c_double * 3), ("tao", C.c_double * 3), ("R2", C.c_double),
+                ("obj", C.c_int32), ("x", C.c_int32), ("y", C.c_int32), ("node", C.c_int32),
+                ("N", C.c_int32), ("newN", C.c_int32)]
+
+
+HITPOINT_DTYPE = np.dtype([("pos", "f8", 3), ("n", "f8", 3), ("v", "f8", 3), ("wgt", "f8", 3),
+                           ("tao", "f8", 3), ("R2", "f8"), ("obj", "i4"), ("x", "i4"), ("y", "i4"),
+                           ("node", "i4"), ("N", "i4"), ("newN", "i4")])
+assert HITPOINT_DTYPE.itemsize == C.sizeof(HitPoint)
+
+
+class Counters(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("photons", "segments", "deposits", "candidates", "accepted",
+                                           "hitpoints", "newton_calls", "eye_segments")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class Timings(C.Structure):
+    _fields_ = [("eye_trace_ms", C.c_double), ("grid_build_ms", C.c_double), ("photon_trace_ms", C.c_double),
+                ("deposit_sort_ms", C.c_double), ("gather_ms", C.c_double), ("resolve_ms", C.c_double),
+                ("gather_launches", C.c_int32), ("trace_launches", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class Collision(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("n", C.c_double * 3), ("color", C.c_double * 3),
+                ("dist", C.c_double), ("obj", C.c_int32), ("inside", C.c_int32)]
+
+
+COLLISION_DTYPE = np.dtype([("pos", "f8", 3), ("n", "f8", 3), ("color", "f8", 3), ("dist", "f8"),
+                            ("obj", "i4"), ("inside", "i4")])
+assert COLLISION_DTYPE.itemsize == C.sizeof(Collision)
+
+# Every symbol include/sppm_abi.h declares, with its ctypes signature.
+ABI_SYMBOLS = {
+    "sppm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "sppm_destroy": (None, [C.c_void_p]),
+    "sppm_last_error": (C.c_char_p, [C.c_void_p]),
+    "sppm_set_scene": (C.c_int, [C.c_void_p, C.POINTER(Scene)]),
+    "sppm_eye_pass": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.c_uint64, C.c_uint32]),
+    "sppm_photon_pass": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]),
+    "sppm_resolve": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
+    "sppm_resolve_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sppm_get_hitpoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "sppm_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
+    "sppm_get_timings": (C.c_int, [C.c_void_p, C.POINTER(Timings)]),
+    "sppm_debug_near_collide": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.c_uint64, C.c_uint32, C.c_void_p]),
+    "sppm_debug_newton": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_int32), C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
+}
+
+
+def bind(lib, symbols):
+    for name, (res, args) in symbols.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def load_library(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the SPPM hot path)")
+    return bind(C.CDLL(path), ABI_SYMBOLS)
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class SppmError(RuntimeError):
+    pass
+
+
+class SppmContext:
+    """One GPU context of libsppm_hip.so (mirrors the sppm_* call sequence)."""
+
+    prefix = "sppm"
+
+    def __init__(self, device_id=0, lib=None):
+        self.lib = lib if lib is not None else load_library()
+        self._ctx = C.c_void_p()
+        rc = self.lib.sppm_create(C.byref(self._ctx), int(device_id))
+        if rc != 0:
+            raise SppmError(f"sppm_create(device {device_id}) failed with {rc}: no usable HIP device?")
+        self.cam = None
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.sppm_last_error(self._ctx)
+            raise SppmError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def close(self):
+        if self._ctx:
+            self.lib.sppm_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_scene(self, scene):
+        """scene: raytrace3_amd.scenes.FlatScene"""
+        self._scene_keepalive = scene
+        self._check(self.lib.sppm_set_scene(self._ctx, C.byref(scene.c_scene)), "sppm_set_scene")
+
+    def eye_pass(self, cam, seed, replica=0):
+        self.cam = cam
+        self._check(self.lib.sppm_eye_pass(self._ctx, C.byref(cam), seed, replica), "sppm_eye_pass")
+
+    def photon_pass(self, rounds, per_round, seed, replica=0, photon_begin=0, photon_count=0):
+        self._check(self.lib.sppm_photon_pass(self._ctx, rounds, per_round, photon_begin, photon_count, seed, replica),
+                    "sppm_photon_pass")
+
+    def resolve(self, accumulate_into=None):
+        h, w = self.cam.h, self.cam.w
+        pic = accumulate_into if accumulate_into is not None else np.zeros((h, w, 3), dtype=np.float64)
+        assert pic.shape == (h, w, 3) and pic.dtype == np.float64 and pic.flags.c_contiguous
+        self._check(self.lib.sppm_resolve(self._ctx, _dptr(pic), 1 if accumulate_into is not None else 0), "sppm_resolve")
+        return pic
+
+    def resolve_device(self, dev_ptr):
+        self._check(self.lib.sppm_resolve_device(self._ctx, C.c_void_p(dev_ptr)), "sppm_resolve_device")
+
+    def hitpoints(self):
+        n = C.c_uint64(0)
+        self._check(self.lib.sppm_get_hitpoints(self._ctx, None, 0, C.byref(n)), "sppm_get_hitpoints")
+        out = np.zeros(n.value, dtype=HITPOINT_DTYPE)
+        if n.value:
+            self._check(self.lib.sppm_get_hitpoints(self._ctx, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)),
+                        "sppm_get_hitpoints")
+        return out
+
+    def counters(self):
+        c = Counters()
+        self._check(self.lib.sppm_get_counters(self._ctx, C.byref(c)), "sppm_get_counters")
+        return c.as_dict()
+
+    def timings(self):
+        t = Timings()
+        self._check(self.lib.sppm_get_timings(self._ctx, C.byref(t)), "sppm_get_timings")
+        return t.as_dict()
+
+    def near_collide(self, org, dir, seed, replica=0):
+        org = np.ascontiguousarray(org, dtype=np.float64)
+        dir = np.ascontiguousarray(dir, dtype=np.float64)
+        n = org.shape[0]
+        out = np.zeros(n, dtype=COLLISION_DTYPE)
+        self._check(self.lib.sppm_debug_near_collide(self._ctx, n, _dptr(org), _dptr(dir), seed, replica,
+                                                     out.ctypes.data_as(C.c_void_p)), "sppm_debug_near_collide")
+        return out
+
+    def newton(self, org, dir, patch, seed, replica=0):
+        org = np.ascontiguousarray(org, dtype=np.float64)
+        dir = np.ascontiguousarray(dir, dtype=np.float64)
+        patch = np.ascontiguousarray(patch, dtype=np.int32)
+        n = org.shape[0]
+        out = np.zeros((n, 3), dtype=np.float64)
+        self._check(self.lib.sppm_debug_newton(self._ctx, n, _dptr(org), _dptr(dir),
+                                               patch.ctypes.data_as(C.POINTER(C.c_int32)), seed, replica, _dptr(out)),
+                    "sppm_debug_newton")
+        return out

@@ -1,0 +1,141 @@
+"""ctypes wrapper of the CPU oracle (oracle/_build/liboracle.so) for the tests.
+
+The oracle is the checker: tests, smoke() and bench.py's cpu_baseline leg are the
+only things that may load it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from raytrace3_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+
+GATHER_GRID, GATHER_BRUTE, GATHER_KDTREE = 0, 1, 2
+
+_D = C.POINTER(C.c_double)
+SYMBOLS = {
+    "oracle_create": (C.c_void_p, [C.c_int, C.c_int]),
+    "oracle_destroy": (None, [C.c_void_p]),
+    "oracle_set_scene": (C.c_int, [C.c_void_p, C.POINTER(abi.Scene)]),
+    "oracle_eye_pass": (C.c_int, [C.c_void_p, C.POINTER(abi.Camera), C.c_uint64, C.c_uint32]),
+    "oracle_photon_pass": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int]),
+    "oracle_resolve": (C.c_int, [C.c_void_p, _D, C.c_int]),
+    "oracle_get_hitpoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "oracle_get_counters": (C.c_int, [C.c_void_p, C.POINTER(abi.Counters)]),
+    "oracle_near_collide": (C.c_int, [C.c_void_p, C.c_uint64, _D, _D, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "oracle_newton": (C.c_int, [C.c_void_p, C.c_uint64, _D, _D, C.POINTER(C.c_int32), C.c_uint64, C.c_uint32, _D]),
+    "oracle_photon_deposits": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _D, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "oracle_bezier_eval": (None, [_D, C.c_double, C.c_double, _D]),
+    "oracle_aabb_intersect": (C.c_int, [_D, _D, _D, _D]),
+    "oracle_refracted": (None, [_D, _D, C.c_double, _D]),
+    "oracle_reflected_unit": (None, [_D, _D, _D]),
+    "oracle_rotated": (None, [_D, _D, C.c_double, _D]),
+    "oracle_rand_refl": (None, [_D, C.c_double, C.c_double, _D]),
+    "oracle_to_int": (C.c_int, [C.c_double]),
+    "oracle_hitpoint_update": (None, [_D, C.POINTER(C.c_int32), _D, C.POINTER(C.c_int32)]),
+    "oracle_mwc_kat": (None, [C.c_int, C.POINTER(C.c_uint32), _D]),
+    "oracle_rng_u32": (C.c_uint32, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "oracle_texture_color_uv": (None, [C.POINTER(abi.Texture), C.c_double, C.c_double, _D]),
+    "oracle_camera_lookat": (None, [_D, _D, C.c_int, C.c_int, C.POINTER(abi.Camera)]),
+    "oracle_camera_emit": (None, [C.POINTER(abi.Camera), C.c_int, C.c_int, _D, _D]),
+    "oracle_plane_intersect": (C.c_int, [C.POINTER(abi.Object), _D, _D, _D]),
+    "oracle_sphere_intersect": (C.c_int, [C.POINTER(abi.Object), _D, _D, _D, C.POINTER(C.c_int)]),
+}
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def load():
+    if not os.path.exists(ORACLE_SO):
+        build()
+    return abi.bind(C.CDLL(ORACLE_SO), SYMBOLS)
+
+
+def dp(a):
+    return a.ctypes.data_as(_D)
+
+
+def vec(*x):
+    return np.array(x, dtype=np.float64)
+
+
+class OracleContext:
+    """Same method names as raytrace3_amd.SppmContext so parity tests read symmetrically."""
+
+    def __init__(self, lib=None, newton_fp32=False, rng_literal=False):
+        self.lib = lib or load()
+        self._ctx = C.c_void_p(self.lib.oracle_create(int(newton_fp32), int(rng_literal)))
+        self.cam = None
+
+    def close(self):
+        if self._ctx:
+            self.lib.oracle_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_scene(self, scene):
+        self._keep = scene
+        assert self.lib.oracle_set_scene(self._ctx, C.byref(scene.c_scene)) == 0
+
+    def eye_pass(self, cam, seed, replica=0):
+        self.cam = cam
+        assert self.lib.oracle_eye_pass(self._ctx, C.byref(cam), seed, replica) == 0
+
+    def photon_pass(self, rounds, per_round, seed, replica=0, photon_begin=0, photon_count=0, mode=GATHER_GRID):
+        assert self.lib.oracle_photon_pass(self._ctx, rounds, per_round, photon_begin, photon_count, seed, replica, mode) == 0
+
+    def resolve(self, accumulate_into=None):
+        h, w = self.cam.h, self.cam.w
+        pic = accumulate_into if accumulate_into is not None else np.zeros((h, w, 3), dtype=np.float64)
+        assert self.lib.oracle_resolve(self._ctx, dp(pic), 1 if accumulate_into is not None else 0) == 0
+        return pic
+
+    def hitpoints(self):
+        n = C.c_uint64(0)
+        self.lib.oracle_get_hitpoints(self._ctx, None, 0, C.byref(n))
+        out = np.zeros(n.value, dtype=abi.HITPOINT_DTYPE)
+        if n.value:
+            self.lib.oracle_get_hitpoints(self._ctx, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n))
+        return out
+
+    def counters(self):
+        c = abi.Counters()
+        self.lib.oracle_get_counters(self._ctx, C.byref(c))
+        return c.as_dict()
+
+    def near_collide(self, org, dir, seed, replica=0):
+        org = np.ascontiguousarray(org, dtype=np.float64)
+        dir = np.ascontiguousarray(dir, dtype=np.float64)
+        out = np.zeros(org.shape[0], dtype=abi.COLLISION_DTYPE)
+        assert self.lib.oracle_near_collide(self._ctx, org.shape[0], dp(org), dp(dir), seed, replica,
+                                            out.ctypes.data_as(C.c_void_p)) == 0
+        return out
+
+    def newton(self, org, dir, patch, seed, replica=0):
+        org = np.ascontiguousarray(org, dtype=np.float64)
+        dir = np.ascontiguousarray(dir, dtype=np.float64)
+        patch = np.ascontiguousarray(patch, dtype=np.int32)
+        out = np.zeros((org.shape[0], 3), dtype=np.float64)
+        assert self.lib.oracle_newton(self._ctx, org.shape[0], dp(org), dp(dir),
+                                      patch.ctypes.data_as(C.POINTER(C.c_int32)), seed, replica, dp(out)) == 0
+        return out
+
+    def deposits(self, rounds, per_round, seed, replica=0, photon_begin=0, photon_count=0, cap=1 << 20):
+        out = np.zeros((cap, 11), dtype=np.float64)
+        n = C.c_uint64(0)
+        rc = self.lib.oracle_photon_deposits(self._ctx, rounds, per_round, photon_begin, photon_count, seed, replica,
+                                             dp(out), cap, C.byref(n))
+        assert rc == 0, rc
+        return out[:n.value]
