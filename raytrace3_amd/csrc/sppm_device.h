@@ -1,0 +1,460 @@
+// sppm_device.h — device-side building blocks of the SPPM hot path (gfx950, wave64).
+//
+// Precision split: ray state, analytic plane / sphere hits, AABB tests, shading
+// directions and gather positions are fp64 (the reference's type, so the 1e-4
+// self-intersection guards of Obj.h:69-76,117-128 behave as they do on the CPU);
+// the Bezier Newton solve — the dominant ALU cost — and all colours, flux and
+// accumulators are fp32.
+//
+// Random numbers are counter-based: a draw is murmur3_32 of
+// (seed_lo, seed_hi, stream, path, (vertex << 8) | purpose, idx) >> 8, times 2^-24,
+// so any lane can evaluate any draw in any order (this is what lets one wavefront
+// spread the 50 Newton restarts of one ray over its lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sppm {
+
+// ---- constants of the reference: Vec3.h:6-14, Raytracer.h:11-13, Bezier.h:6
+#define SPPM_EPS 1e-4
+#define SPPM_PI 3.1415926
+#define SPPM_PI_INV 0.3183098862
+#define SPPM_MAX_NUM 1e20
+#define SPPM_MAX_DEP 13
+#define SPPM_INIT_R2 2.0
+#define SPPM_NEWTON_ITERS 10
+#define SPPM_NEWTON_RESTARTS 50
+
+enum { P_EMIT = 0, P_NEWTON = 1, P_ROULETTE = 2, P_DIFFUSE = 3 };
+enum { D_EYE = 0, D_PHOTON = 1 };
+enum { OBJ_PLANE = 0, OBJ_SPHERE = 1, OBJ_BEZIER = 2 };
+enum { F_DIFF = 1, F_REFL = 2, F_REFR = 4 };
+
+struct DevObject {
+    double p0[3];
+    double n[3];
+    double radius;
+    double refrn;
+    double bmin[3];
+    double bmax[3];
+    double diffr, reflr, refrr, allr;   // Obj.h:11-16
+    float color[3];
+    float diff[3];
+    float refl[3];
+    float refr[3];
+    int type, texture, first_patch, n_patches;
+    int flags, pad;
+};
+
+struct TexDesc {
+    int rows, cols;
+    unsigned offset;   // first texel in the packed uchar4 array
+    int pad;
+};
+
+struct DevLight {
+    double pos[3];
+    float flux[3];     // color * PI * 4, Light.h:10
+    float pad;
+};
+
+// Scene tables staged in LDS by every workgroup: objects | patch AABBs | control points.
+struct SceneView {
+    const DevObject* objs;      // LDS
+    const double* patch_box;    // LDS, n_patches x 6 (pmin, pmax)
+    const float* patch_cp;      // LDS, n_patches x 48
+    int n_objs;
+    int n_patches;
+    const TexDesc* tex;         // global
+    const uchar4* texels;       // global
+};
+
+// ------------------------------------------------------------------ RNG
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__device__ __forceinline__ uint32_t mm3(uint32_t h, uint32_t k) {
+    k *= 0xcc9e2d51u; k = rotl32(k, 15); k *= 0x1b873593u;
+    h ^= k; h = rotl32(h, 13); h = h * 5u + 0xe6546b64u;
+    return h;
+}
+__device__ __forceinline__ uint32_t fmix3(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+// hash state after (seed_lo, seed_hi, stream)
+__device__ __forceinline__ uint32_t rng_base(uint64_t seed, uint32_t stream) {
+    uint32_t h = 0x9747b28cu;
+    h = mm3(h, (uint32_t)seed);
+    h = mm3(h, (uint32_t)(seed >> 32));
+    return mm3(h, stream);
+}
+// hash state after (.., path, (vertex << 8) | purpose)
+__device__ __forceinline__ uint32_t rng_sub(uint32_t base, uint32_t path, uint32_t vertex, uint32_t purpose) {
+    return mm3(mm3(base, path), (vertex << 8) | purpose);
+}
+__device__ __forceinline__ uint32_t rng_bits(uint32_t sub, uint32_t idx) { return fmix3(mm3(sub, idx) ^ 24u) >> 8; }
+__device__ __forceinline__ double rng_u01(uint32_t sub, uint32_t idx) { return (double)rng_bits(sub, idx) * (1.0 / 16777216.0); }
+__device__ __forceinline__ float rng_u01f(uint32_t sub, uint32_t idx) { return (float)rng_bits(sub, idx) * (1.0f / 16777216.0f); }
+
+// ------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+__device__ __forceinline__ int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ uint32_t bcast_u(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+__device__ __forceinline__ float bcast_f(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+__device__ __forceinline__ double bcast_d(double v, int src) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ uint64_t bcast_u64(uint64_t v, int src) {
+    uint32_t lo = bcast_u((uint32_t)v, src), hi = bcast_u((uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------ Vec3.h in fp64
+struct d3 { double x, y, z; };
+__device__ __forceinline__ d3 mk(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ d3 operator+(d3 a, d3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ d3 operator-(d3 a, d3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ d3 operator*(d3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ d3 neg(d3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ d3 cross(d3 a, d3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ d3 ld3(const double* p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ double comp(d3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+__device__ __forceinline__ bool is_zero(double v) { return fabs(v) < SPPM_EPS; }           // Vec3.h:23
+__device__ __forceinline__ d3 get_unit(d3 v) {                                             // Vec3.h:56 (and Normalize, :48-55)
+    double mo = sqrt(dot(v, v));
+    return is_zero(mo) ? v : v * (1.0 / mo);
+}
+__device__ __forceinline__ d3 get_refl(d3 v, d3 n) { return v - n * (2 * dot(v, n)); }     // Vec3.h:80-83
+__device__ __forceinline__ d3 get_anormal(d3 v) {                                          // Vec3.h:85-89
+    return (v.x == 0 && v.y == 0) ? mk(1, 0, 0) : get_unit(mk(v.y, -v.x, 0));
+}
+__device__ __forceinline__ d3 rotated(d3 v, d3 a, double angle) {                          // Vec3.h:99-115
+    if (fabs(angle) < SPPM_EPS) return v;
+    double cost = cos(angle), sint = sin(angle);
+    d3 r;
+    r.x = v.x * (a.x * a.x + (1 - a.x * a.x) * cost) + v.y * (a.x * a.y * (1 - cost) - a.z * sint) +
+          v.z * (a.x * a.z * (1 - cost) + a.y * sint);
+    r.y = v.x * (a.y * a.x * (1 - cost) + a.z * sint) + v.y * (a.y * a.y + (1 - a.y * a.y) * cost) +
+          v.z * (a.y * a.z * (1 - cost) - a.x * sint);
+    r.z = v.x * (a.z * a.x * (1 - cost) - a.y * sint) + v.y * (a.z * a.y * (1 - cost) + a.x * sint) +
+          v.z * (a.z * a.z + (1 - a.z * a.z) * cost);
+    return r;
+}
+__device__ __forceinline__ d3 rand_refl(d3 n, double u1, double u2) {                      // Vec3.h:90-98
+    double theta = acos(sqrt(u1));
+    double phi = 2 * SPPM_PI * u2;
+    d3 ret = rotated(n, get_anormal(n), theta);
+    return get_unit(rotated(ret, n, phi));
+}
+__device__ __forceinline__ d3 refracted(d3 I, d3 N, double n) {                            // Vec3.h:124-134
+    double cosI = -dot(N, I);
+    double cosR2 = 1 - (1 - cosI * cosI) * (n * n);
+    return (cosR2 > SPPM_EPS) ? I * n + N * (n * cosI - sqrt(cosR2)) : get_refl(I, N);
+}
+
+// ------------------------------------------------------------------ Element.h:61-72 Texture::colorUV
+__device__ __forceinline__ void color_uv(const TexDesc t, const uchar4* __restrict__ texels, double u, double v, float out[3]) {
+    int rows = t.rows, cols = t.cols;
+    double row = (u - floor(u)) * rows, col = (v - floor(v)) * cols;
+    int r1 = (int)floor(row + 1e-10), r2 = r1 + 1;
+    int c1 = (int)floor(col + 1e-10), c2 = c1 + 1;
+    double detR = r2 - row, detC = c2 - col;
+    r1 = (r1 >= 0) ? (r1 >= rows ? 0 : r1) : (rows - 1);
+    c1 = (c1 >= 0) ? (c1 >= cols ? 0 : c1) : (cols - 1);
+    r2 = (r2 < rows) ? r2 : 0;
+    c2 = (c2 < cols) ? c2 : 0;
+    r2 = r2 < 0 ? 0 : r2;  // memory-safety guard for NaN coordinates (the reference would index out of bounds)
+    c2 = c2 < 0 ? 0 : c2;
+    const uchar4* base = texels + t.offset;
+    uchar4 a = base[(size_t)r1 * cols + c1], b = base[(size_t)r1 * cols + c2];
+    uchar4 c = base[(size_t)r2 * cols + c1], d = base[(size_t)r2 * cols + c2];
+    double wa = detR * detC, wb = detR * (1 - detC), wc = (1 - detR) * detC, wd = (1 - detR) * (1 - detC);
+    const double k = 1.0 / 255.0;
+    out[0] = (float)((a.x * wa + b.x * wb + c.x * wc + d.x * wd) * k);
+    out[1] = (float)((a.y * wa + b.y * wb + c.y * wc + d.y * wd) * k);
+    out[2] = (float)((a.z * wa + b.z * wb + c.z * wc + d.z * wd) * k);
+}
+
+// ------------------------------------------------------------------ Bezier.h:20-51 AABBbox::intersect
+// Entry faces only, t > 0: an origin inside the box reports a miss.
+__device__ __forceinline__ bool aabb_hit(const double* __restrict__ box, d3 o, d3 d) {
+    d3 pmin = ld3(box), pmax = ld3(box + 3);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double di = comp(d, i);
+        if (!is_zero(di)) {
+            double t = ((di > 0 ? comp(pmin, i) : comp(pmax, i)) - comp(o, i)) / di;
+            if (t > 0) {
+                d3 c = o + d * t;
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                    if (j != i)
+                        if (comp(pmax, j) < comp(c, j) || comp(pmin, j) > comp(c, j)) ok = false;
+                if (ok) return true;
+            }
+        }
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------ bicubic Bernstein evaluation (Bezier.h:69-111), fp32
+// S(u,v) = sum_i sum_k P[4i+k] b_k(u) b_i(v): u runs along the fast index.
+struct f3 { float x, y, z; };
+__device__ __forceinline__ void bern(float t, float b[4], float d[4]) {
+    float m = 1.0f - t;
+    b[0] = m * m * m; b[1] = 3.0f * t * m * m; b[2] = 3.0f * t * t * m; b[3] = t * t * t;
+    d[0] = -3.0f * m * m; d[1] = 3.0f * m * m - 6.0f * t * m; d[2] = 6.0f * t * m - 3.0f * t * t; d[3] = 3.0f * t * t;
+}
+// P: 48 floats (wave-uniform values held in registers).  Returns S, dS/du, dS/dv.
+__device__ __forceinline__ void patch_eval(const float* P, float u, float v, f3& S, f3& Su, f3& Sv) {
+    float bu[4], du[4], bv[4], dv[4];
+    bern(u, bu, du);
+    bern(v, bv, dv);
+    S = {0, 0, 0}; Su = {0, 0, 0}; Sv = {0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float* r = P + 12 * i;
+        float ax = r[0] * bu[0] + r[3] * bu[1] + r[6] * bu[2] + r[9] * bu[3];
+        float ay = r[1] * bu[0] + r[4] * bu[1] + r[7] * bu[2] + r[10] * bu[3];
+        float az = r[2] * bu[0] + r[5] * bu[1] + r[8] * bu[2] + r[11] * bu[3];
+        float dx = r[0] * du[0] + r[3] * du[1] + r[6] * du[2] + r[9] * du[3];
+        float dy = r[1] * du[0] + r[4] * du[1] + r[7] * du[2] + r[10] * du[3];
+        float dz = r[2] * du[0] + r[5] * du[1] + r[8] * du[2] + r[11] * du[3];
+        S.x += ax * bv[i]; S.y += ay * bv[i]; S.z += az * bv[i];
+        Sv.x += ax * dv[i]; Sv.y += ay * dv[i]; Sv.z += az * dv[i];
+        Su.x += dx * bv[i]; Su.y += dy * bv[i]; Su.z += dz * bv[i];
+    }
+}
+__device__ __forceinline__ f3 patch_point(const float* P, float u, float v) {
+    float bu[4], du[4], bv[4], dv[4];
+    bern(u, bu, du);
+    bern(v, bv, dv);
+    f3 S = {0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float* r = P + 12 * i;
+        S.x += (r[0] * bu[0] + r[3] * bu[1] + r[6] * bu[2] + r[9] * bu[3]) * bv[i];
+        S.y += (r[1] * bu[0] + r[4] * bu[1] + r[7] * bu[2] + r[10] * bu[3]) * bv[i];
+        S.z += (r[2] * bu[0] + r[5] * bu[1] + r[8] * bu[2] + r[11] * bu[3]) * bv[i];
+    }
+    return S;
+}
+
+// One Newton restart, Bezier.h:117-140: 10 steps of x -= J^-1 (org + dir t - S(u,v)),
+// J = [dir | -Su | -Sv], from (0, u0, v0); every iterate with residual^2 < 1e-4 and
+// u, v in [0,1] is a candidate; returns this restart's first minimum-t candidate.
+__device__ __forceinline__ void newton_restart(const float* P, f3 o, f3 d, float u0, float v0, float& best_t, float& best_u, float& best_v) {
+    float t = 0.0f, u = u0, v = v0;
+    best_t = (float)SPPM_MAX_NUM; best_u = 0; best_v = 0;
+#pragma unroll 1
+    for (int it = 0; it < SPPM_NEWTON_ITERS; it++) {
+        f3 S, Su, Sv;
+        patch_eval(P, u, v, S, Su, Sv);
+        float rx = o.x + d.x * t - S.x, ry = o.y + d.y * t - S.y, rz = o.z + d.z * t - S.z;
+        if (it > 0) {  // candidate test of the iterate produced by the previous step (Bezier.h:133-139)
+            float res2 = rx * rx + ry * ry + rz * rz;
+            if (res2 < (float)SPPM_EPS && u <= 1.0f && u >= 0.0f && v >= 0.0f && v <= 1.0f && t < best_t) {
+                best_t = t; best_u = u; best_v = v;
+            }
+        }
+        // columns a = d, b = -Su, c = -Sv; inverse rows = (b x c, c x a, a x b) / det; det == 0 -> zero matrix
+        float c0x = Su.y * Sv.z - Su.z * Sv.y, c0y = Su.z * Sv.x - Su.x * Sv.z, c0z = Su.x * Sv.y - Su.y * Sv.x;  // b x c
+        float c1x = d.y * Sv.z - d.z * Sv.y, c1y = d.z * Sv.x - d.x * Sv.z, c1z = d.x * Sv.y - d.y * Sv.x;        // c x a = d x Sv
+        float c2x = Su.y * d.z - Su.z * d.y, c2y = Su.z * d.x - Su.x * d.z, c2z = Su.x * d.y - Su.y * d.x;        // a x b = Su x d
+        float det = d.x * c0x + d.y * c0y + d.z * c0z;
+        float inv = (det == 0.0f) ? 0.0f : 1.0f / det;
+        t -= (c0x * rx + c0y * ry + c0z * rz) * inv;
+        u -= (c1x * rx + c1y * ry + c1z * rz) * inv;
+        v -= (c2x * rx + c2y * ry + c2z * rz) * inv;
+    }
+    f3 S = patch_point(P, u, v);
+    float rx = o.x + d.x * t - S.x, ry = o.y + d.y * t - S.y, rz = o.z + d.z * t - S.z;
+    float res2 = rx * rx + ry * ry + rz * rz;
+    if (res2 < (float)SPPM_EPS && u <= 1.0f && u >= 0.0f && v >= 0.0f && v <= 1.0f && t < best_t) {
+        best_t = t; best_u = u; best_v = v;
+    }
+}
+
+// Bezier3::newton (Bezier.h:112-159) for ONE (ray, patch), all 64 lanes cooperating:
+// lane r < 50 runs restart r; the result is the minimum-t candidate over all
+// restarts, ties to the lowest restart (the reference keeps the first pushed
+// minimum).  o, d, sub (the ray's NEWTON hash state) and patch are wave-uniform.
+// Returns a wave-uniform (t,u,v); t = 1e20 when nothing converged.
+__device__ __forceinline__ void newton_coop(const float* __restrict__ cp_lds, int patch, f3 o, f3 d, uint32_t sub, float& rt, float& ru, float& rv) {
+    const int lane = lane_id();
+    float P[48];
+    const float* src = cp_lds + patch * 48;
+#pragma unroll
+    for (int k = 0; k < 48; k++) P[k] = src[k];
+    float bt = (float)SPPM_MAX_NUM, bu = 0, bv = 0;
+    if (lane < SPPM_NEWTON_RESTARTS) {
+        float u0 = rng_u01f(sub, (uint32_t)patch * 128u + (uint32_t)lane * 2u + 0u);
+        float v0 = rng_u01f(sub, (uint32_t)patch * 128u + (uint32_t)lane * 2u + 1u);
+        newton_restart(P, o, d, u0, v0, bt, bu, bv);
+    }
+    // min over lanes of (t, lane)
+    int who = lane;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        float ot = __shfl_xor(bt, off, 64);
+        int ow = __shfl_xor(who, off, 64);
+        if (ot < bt || (ot == bt && ow < who)) { bt = ot; who = ow; }
+    }
+    who = bcast_i(who, 0);
+    rt = bcast_f(bt, 0);
+    ru = bcast_f(bu, who);
+    rv = bcast_f(bv, who);
+}
+
+// ------------------------------------------------------------------ Scene::NearCollide (Scene.h:165-182)
+struct Hit {
+    d3 pos, n;
+    float color[3];
+    double dist;
+    int obj;      // -1 = none
+    int inside;
+};
+
+// Bezier3Obj::GetIntersect (Bezier.h:240-282) for the lanes of one wave.  `need` marks
+// lanes whose ray passed the object AABB.  For each such ray in turn the wave tests the
+// patch AABBs one per lane, then solves every hit patch cooperatively.  On return the
+// ray's lane holds (t,u,v,patch) of the nearest accepted patch or patch = -1.
+__device__ __forceinline__ void bezier_coop(const SceneView& S, const DevObject& ob, bool need, d3 o, d3 d, uint32_t sub,
+                                            float& out_t, float& out_u, float& out_v, int& out_patch, uint32_t& newton_calls) {
+    const int lane = lane_id();
+    out_patch = -1; out_t = (float)SPPM_MAX_NUM; out_u = 0; out_v = 0;
+    uint64_t m = __ballot(need);
+    while (m) {
+        int src = __ffsll((unsigned long long)m) - 1;
+        m &= m - 1;
+        d3 so = mk(bcast_d(o.x, src), bcast_d(o.y, src), bcast_d(o.z, src));
+        d3 sd = mk(bcast_d(d.x, src), bcast_d(d.y, src), bcast_d(d.z, src));
+        uint32_t ssub = bcast_u(sub, src);
+        f3 fo = {(float)so.x, (float)so.y, (float)so.z}, fd = {(float)sd.x, (float)sd.y, (float)sd.z};
+        float pt = (float)SPPM_MAX_NUM, pu = (float)SPPM_MAX_NUM, pv = (float)SPPM_MAX_NUM;  // para = MAX_VEC3
+        int pidx = -1;
+        for (int base = 0; base < ob.n_patches; base += 64) {
+            int p = ob.first_patch + base + lane;
+            bool ph = (base + lane < ob.n_patches) && aabb_hit(S.patch_box + 6 * p, so, sd);   // Bezier3::intersect, Bezier.h:176-186
+            uint64_t pm = __ballot(ph);
+            while (pm) {
+                int pi = ob.first_patch + base + (__ffsll((unsigned long long)pm) - 1);
+                pm &= pm - 1;
+                float t, u, v;
+                newton_coop(S.patch_cp, pi, fo, fd, ssub, t, u, v);
+                newton_calls += (lane == 0) ? 1u : 0u;
+                const float e = (float)SPPM_EPS;
+                // Bezier.h:251-259 (a patch whose minimum-t candidate is negative is dropped as a whole)
+                if (t < e || t > pt || u < -e || u > 1 + e || v < -e || v > 1 + e) continue;
+                if (t < pt) { pt = t; pu = u; pv = v; pidx = pi; }
+            }
+        }
+        if (lane == src) { out_t = pt; out_u = pu; out_v = pv; out_patch = pidx; }
+    }
+}
+
+// All lanes of the wave must call this together (it contains wave-cooperative
+// sections); lanes with active = false take part but get obj = -1.
+__device__ __forceinline__ Hit near_collide(const SceneView& S, bool active, d3 o, d3 d, uint32_t newton_sub, uint32_t& newton_calls) {
+    double mindist = SPPM_MAX_NUM;
+    int best = -1, best_inside = 0, best_patch = -1;
+    float best_u = 0, best_v = 0, best_t = 0;
+    for (int a = 0; a < S.n_objs; a++) {
+        const DevObject& ob = S.objs[a];
+        if (ob.type == OBJ_PLANE) {                                                       // Obj.h:65-85
+            d3 n = ld3(ob.n);
+            double project = dot(d, n);
+            if (active && !is_zero(project)) {
+                double dist = dot(ld3(ob.p0) - o, n) / project;
+                if (dist > SPPM_EPS && dist < mindist) { mindist = dist; best = a; best_inside = 0; }
+            }
+        } else if (ob.type == OBJ_SPHERE) {                                               // Obj.h:111-139
+            d3 L = ld3(ob.p0) - o;
+            double project = dot(L, d);
+            double det2 = ob.radius * ob.radius - (dot(L, L) - project * project);
+            if (active && !(det2 < SPPM_EPS)) {
+                double det = sqrt(det2);
+                double dist1 = project - det, dist2 = project + det;
+                if (!(dist2 < SPPM_EPS)) {
+                    double dist = (dist1 > SPPM_EPS) ? dist1 : dist2;
+                    if (dist < mindist) { mindist = dist; best = a; best_inside = (dist1 < SPPM_EPS) ? 1 : 0; }
+                }
+            }
+        } else {                                                                          // Bezier.h:240-282
+            bool need = active && aabb_hit(ob.bmin, o, d);
+            float t, u, v;
+            int patch;
+            bezier_coop(S, ob, need, o, d, newton_sub, t, u, v, patch, newton_calls);
+            if (need && patch >= 0 && (double)t < mindist) {
+                mindist = (double)t; best = a; best_inside = 0;
+                best_patch = patch; best_t = t; best_u = u; best_v = v;
+            }
+        }
+    }
+    // Collision of the winner only (GetColor is a pure function, so evaluating it for
+    // the nearest object alone gives what the reference's per-object evaluation gives).
+    Hit h;
+    h.obj = best; h.dist = mindist; h.inside = best_inside;
+    h.pos = mk(0, 0, 0); h.n = mk(0, 0, 0); h.color[0] = h.color[1] = h.color[2] = 0;
+    if (best >= 0) {
+        const DevObject& ob = S.objs[best];
+        h.pos = o + d * mindist;
+        h.color[0] = ob.color[0]; h.color[1] = ob.color[1]; h.color[2] = ob.color[2];
+        if (ob.type == OBJ_PLANE) {
+            h.n = ld3(ob.n);
+            if (ob.texture >= 0) {                                                        // Obj.h:86-100
+                d3 nn = ld3(ob.n), p0 = ld3(ob.p0);
+                int ndir = 0;
+                for (int i = 0; i < 3; i++) if (comp(nn, i) != 0) ndir = i;
+                int vdex = (ndir + 2) % 3, udex = (ndir + 1) % 3;
+                double v = 0.5 + (comp(h.pos, vdex) - comp(p0, vdex)) / 400.0;
+                double u = 0.5 + (comp(h.pos, udex) - comp(p0, udex)) / 300.0;
+                color_uv(S.tex[ob.texture], S.texels, u, v, h.color);
+            }
+        } else if (ob.type == OBJ_SPHERE) {
+            d3 c = ld3(ob.p0);
+            h.n = get_unit(h.pos - c);
+            if (ob.texture >= 0) {                                                        // Obj.h:140-153
+                const d3 texU = mk(0, 0.70710678118654757, -0.70710678118654757), texV = mk(1, 0, 0);
+                d3 N = h.n;
+                double theta = acos(dot(N, texV));
+                double t = dot(N, texU) / sin(theta);
+                t = (t >= -1) ? t : -1;
+                t = (t <= 1) ? t : 1;
+                double phi = acos(t);
+                double u = theta / SPPM_PI, v = phi / (2 * SPPM_PI);
+                v = (dot(N, cross(texU, texV)) < 0) ? (1 - v) : v;
+                color_uv(S.tex[ob.texture], S.texels, u, v, h.color);
+            }
+        } else {
+            // normal = Su x Sv at the winning (u, v), turned against the ray (Bezier.h:267-273)
+            float P[48];
+            const float* src = S.patch_cp + best_patch * 48;
+#pragma unroll
+            for (int k = 0; k < 48; k++) P[k] = src[k];
+            f3 Sp, Su, Sv;
+            patch_eval(P, best_u, best_v, Sp, Su, Sv);
+            d3 N = cross(mk(Su.x, Su.y, Su.z), mk(Sv.x, Sv.y, Sv.z));
+            if (dot(N, d) > 0) N = neg(N);
+            h.n = get_unit(N);
+            // GetColor(u, t): the second texture coordinate is the ray parameter (Bezier.h:278)
+            if (ob.texture >= 0) color_uv(S.tex[ob.texture], S.texels, (double)best_u, (double)best_t, h.color);
+        }
+    }
+    return h;
+}
+
+}  // namespace sppm

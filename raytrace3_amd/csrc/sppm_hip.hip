@@ -1,0 +1,1036 @@
+// sppm_hip.hip — HIP kernels (gfx950) and the C-ABI of include/sppm_abi.h.
+//
+// Pipeline of one replica:
+//   eye pass   : k_eye_trace (one lane per eye path, wave-cooperative Bezier Newton)
+//                -> raw HitPoints -> hashed grid: k_hp_count / k_scan / k_hp_scatter
+//   photon pass: per batch  k_photon_trace (persistent wavefronts, lanes refilled from a
+//                photon counter; diffuse hits appended as deposit records, bucket
+//                histogram on the fly) -> k_scan -> k_dep_scatter (deposits sorted by
+//                grid bucket) -> k_gather (one wave per tile of 64 sorted HitPoints,
+//                lanes stream the deposits of the 27 neighbour cells coalesced, the
+//                flux update is reduced across the wave and written by the tile's
+//                owner: no global atomics on HitPoints)
+//   resolve    : k_resolve (tao -> flux image)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sppm_abi.h"
+#include "sppm_device.h"
+
+using namespace sppm;
+
+// ------------------------------------------------------------------ device records
+struct __attribute__((aligned(32))) PosKey { double x, y, z; uint64_t key; };
+struct __attribute__((aligned(32))) DepB { float nx, ny, nz, fr, fg, fb; uint32_t bucket, pad; };
+struct RawHit { double pos[3]; float n[3]; float v[3]; float wgt[3]; int pix, node, obj; };
+struct HpMeta { float v[3]; int node, obj, N; };
+struct EyeTask { double o[3]; double d[3]; float wgt[3]; int pix, node, dep; };
+
+struct SceneParams {
+    const char* blob;
+    int blob_bytes, off_box, off_cp, n_objs, n_patches;
+    const TexDesc* tex;
+    const uchar4* texels;
+};
+
+struct DevCounters {
+    unsigned long long photons, segments, deposits, candidates, accepted, newton_calls, eye_segments;
+    unsigned int overflow;   // bit0 hitpoint capacity, bit1 eye task queue, bit2 deposit capacity
+    unsigned int pad;
+};
+
+struct GridParams {
+    double inv_cs;       // 1 / cell size
+    uint32_t mask;       // bucket count - 1 (power of two)
+};
+
+// ------------------------------------------------------------------ grid helpers
+#define CELL_OFF 1048576   // 2^20
+__device__ __forceinline__ uint32_t cell_coord(double p, double inv_cs) {
+    double f = floor(p * inv_cs);
+    f = fmin(fmax(f, -1048574.0), 1048574.0);   // keeps every 21-bit field in [2, 2^21 - 2]: +-1 never carries
+    return (uint32_t)((int)f + CELL_OFF);
+}
+__device__ __forceinline__ uint64_t cell_key(d3 p, double inv_cs) {
+    return ((uint64_t)cell_coord(p.x, inv_cs) << 42) | ((uint64_t)cell_coord(p.y, inv_cs) << 21) | (uint64_t)cell_coord(p.z, inv_cs);
+}
+__device__ __forceinline__ uint32_t key_bucket(uint64_t key, uint32_t mask) {
+    uint32_t ix = (uint32_t)(key >> 42) & 0x1fffffu, iy = (uint32_t)(key >> 21) & 0x1fffffu, iz = (uint32_t)key & 0x1fffffu;
+    uint32_t h = (ix * 73856093u) ^ (iy * 19349663u) ^ (iz * 83492791u);
+    return fmix3(h) & mask;
+}
+
+// ------------------------------------------------------------------ LDS scene staging
+extern __shared__ double lds_scene[];
+__device__ __forceinline__ SceneView stage_scene(const SceneParams& sp) {
+    const uint32_t* src = (const uint32_t*)sp.blob;
+    uint32_t* dst = (uint32_t*)lds_scene;
+    for (int i = threadIdx.x; i < sp.blob_bytes / 4; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    SceneView S;
+    const char* base = (const char*)lds_scene;
+    S.objs = (const DevObject*)base;
+    S.patch_box = (const double*)(base + sp.off_box);
+    S.patch_cp = (const float*)(base + sp.off_cp);
+    S.n_objs = sp.n_objs;
+    S.n_patches = sp.n_patches;
+    S.tex = sp.tex;
+    S.texels = sp.texels;
+    return S;
+}
+
+// wave-aggregated slot allocation: every lane calls it; lanes with want = true get
+// consecutive slots from *counter.
+__device__ __forceinline__ unsigned long long wave_alloc(bool want, unsigned long long* counter) {
+    uint64_t m = __ballot(want);
+    if (m == 0) return 0;
+    int leader = __ffsll((unsigned long long)m) - 1;
+    unsigned long long base = 0;
+    if (lane_id() == leader) base = atomicAdd(counter, (unsigned long long)__popcll(m));
+    base = bcast_u64(base, leader);
+    return base + (unsigned long long)__popcll(m & lanemask_lt());
+}
+
+__device__ __forceinline__ void flush_counter(unsigned long long* dst, uint32_t v) {
+    uint32_t s = wave_sum_u(v);
+    if (lane_id() == 0 && s) atomicAdd(dst, (unsigned long long)s);
+}
+
+// ------------------------------------------------------------------ pass 1: eye trace
+struct EyeParams {
+    double pos[3], dir[3], du[3], dv[3];
+    int w, h;
+    int n_tasks;
+    const EyeTask* tasks_in;     // nullptr: primary rays from the camera
+    RawHit* hits; unsigned long long* n_hits; unsigned long long hit_cap;
+    EyeTask* tasks_out; unsigned long long* n_tasks_out; unsigned long long task_cap;
+    uint32_t rng;                // rng_base(seed, replica * 4 + D_EYE)
+    DevCounters* counters;
+};
+
+// RayTracer::GetHitPoint + ViewTrace (Raytracer.h:102-116, :296-357).  A lane follows one
+// eye path; when a material has both a reflective and a refractive lobe the refraction
+// branch is queued as a new task and traced by a follow-up launch.
+__global__ void __launch_bounds__(256) k_eye_trace(SceneParams sp, EyeParams ep) {
+    SceneView S = stage_scene(sp);
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = tid < ep.n_tasks;
+    d3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+    float wgt[3] = {1, 1, 1};
+    int pix = 0, node = 0, dep = 0;
+    if (active) {
+        if (ep.tasks_in == nullptr) {
+            pix = tid;
+            int row = pix / ep.w, col = pix % ep.w;
+            o = ld3(ep.pos);
+            // Camera::emit(y = row, x = col), Camera.h:18-22
+            d3 dd = ld3(ep.du) * ((col + 0.5) / ep.w - 0.5) + ld3(ep.dv) * ((row + 0.5) / ep.h - 0.5) + ld3(ep.dir);
+            d = get_unit(dd);
+        } else {
+            const EyeTask t = ep.tasks_in[tid];
+            o = ld3(t.o); d = ld3(t.d);
+            wgt[0] = t.wgt[0]; wgt[1] = t.wgt[1]; wgt[2] = t.wgt[2];
+            pix = t.pix; node = t.node; dep = t.dep;
+        }
+    }
+    uint32_t ncalls = 0, nseg = 0;
+    while (__any(active)) {
+        uint32_t sub = rng_sub(ep.rng, (uint32_t)pix, (uint32_t)node, P_NEWTON);
+        Hit hit = near_collide(S, active, o, d, sub, ncalls);
+        if (active) nseg++;
+        if (active && hit.obj < 0) active = false;
+        bool emit_hp = false, push = false;
+        RawHit rh;
+        EyeTask task;
+        if (active) {
+            dep++;
+            const DevObject& ob = S.objs[hit.obj];
+            float bw[3] = {hit.color[0] * wgt[0], hit.color[1] * wgt[1], hit.color[2] * wgt[2]};
+            if (ob.flags & F_DIFF) {                                                      // Raytracer.h:312-319
+                emit_hp = true;
+                rh.pos[0] = hit.pos.x; rh.pos[1] = hit.pos.y; rh.pos[2] = hit.pos.z;
+                rh.n[0] = (float)hit.n.x; rh.n[1] = (float)hit.n.y; rh.n[2] = (float)hit.n.z;
+                rh.v[0] = (float)d.x; rh.v[1] = (float)d.y; rh.v[2] = (float)d.z;
+                rh.wgt[0] = bw[0] * ob.diff[0]; rh.wgt[1] = bw[1] * ob.diff[1]; rh.wgt[2] = bw[2] * ob.diff[2];
+                rh.pix = pix; rh.node = node; rh.obj = hit.obj;
+            }
+            const bool has_refl = ob.flags & F_REFL, has_refr = ob.flags & F_REFR;
+            d3 refl_d = mk(0, 0, 0), refr_d = mk(0, 0, 0);
+            if (has_refl) refl_d = get_unit(get_refl(d, hit.n));                          // Raytracer.h:320-326
+            if (has_refr) {                                                               // Raytracer.h:327-336
+                double refrn = hit.inside ? ob.refrn : 1 / ob.refrn;
+                refr_d = get_unit(refracted(d, hit.inside ? neg(hit.n) : hit.n, refrn));
+            }
+            if (dep > SPPM_MAX_DEP) {
+                active = false;  // the next NearCollide result would be discarded (Raytracer.h:303-309)
+            } else if (has_refl) {
+                if (has_refr) {
+                    push = true;
+                    task.o[0] = hit.pos.x; task.o[1] = hit.pos.y; task.o[2] = hit.pos.z;
+                    task.d[0] = refr_d.x; task.d[1] = refr_d.y; task.d[2] = refr_d.z;
+                    task.wgt[0] = bw[0] * ob.refr[0]; task.wgt[1] = bw[1] * ob.refr[1]; task.wgt[2] = bw[2] * ob.refr[2];
+                    task.pix = pix; task.node = 2 * node + 2; task.dep = dep;
+                }
+                wgt[0] = bw[0] * ob.refl[0]; wgt[1] = bw[1] * ob.refl[1]; wgt[2] = bw[2] * ob.refl[2];
+                o = hit.pos; d = refl_d; node = 2 * node + 1;
+            } else if (has_refr) {
+                wgt[0] = bw[0] * ob.refr[0]; wgt[1] = bw[1] * ob.refr[1]; wgt[2] = bw[2] * ob.refr[2];
+                o = hit.pos; d = refr_d; node = 2 * node + 2;
+            } else {
+                active = false;
+            }
+        }
+        unsigned long long slot = wave_alloc(emit_hp, ep.n_hits);
+        if (emit_hp) {
+            if (slot < ep.hit_cap) ep.hits[slot] = rh;
+            else atomicOr(&ep.counters->overflow, 1u);
+        }
+        unsigned long long tslot = wave_alloc(push, ep.n_tasks_out);
+        if (push) {
+            if (tslot < ep.task_cap) ep.tasks_out[tslot] = task;
+            else atomicOr(&ep.counters->overflow, 2u);
+        }
+    }
+    flush_counter(&ep.counters->newton_calls, ncalls);
+    flush_counter(&ep.counters->eye_segments, nseg);
+}
+
+// ------------------------------------------------------------------ hashed grid over HitPoints
+// (replaces the flann kd-tree build, Raytracer.h:370-380)
+__global__ void k_hp_count(const RawHit* hits, uint32_t n, GridParams g, uint32_t* bucket_of, uint32_t* count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t key = cell_key(ld3(hits[i].pos), g.inv_cs);
+    uint32_t b = key_bucket(key, g.mask);
+    bucket_of[i] = b;
+    atomicAdd(&count[b], 1u);
+}
+
+// start[i] = sum_{j<i} cnt[j] for i in [0, n]; one workgroup.
+__global__ void __launch_bounds__(1024) k_scan(const uint32_t* cnt, uint32_t* start, uint32_t n) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t chunk = (n + 1023u) / 1024u;
+    const uint32_t b = t * chunk, e = min(n, b + chunk);
+    uint32_t s = 0;
+    for (uint32_t i = b; i < e; i++) s += cnt[i];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t v = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - s;
+    for (uint32_t i = b; i < e; i++) { start[i] = run; run += cnt[i]; }
+    if (t == 1023) start[n] = part[1023];
+}
+
+__global__ void k_hp_scatter(const RawHit* hits, uint32_t n, GridParams g, const uint32_t* bucket_of, const uint32_t* start,
+                             uint32_t* cursor, PosKey* hp_pos, float4* hp_nr, float4* hp_wgt, float4* hp_tao, HpMeta* hp_meta) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const RawHit h = hits[i];
+    uint32_t b = bucket_of[i];
+    uint32_t s = start[b] + atomicAdd(&cursor[b], 1u);
+    PosKey pk; pk.x = h.pos[0]; pk.y = h.pos[1]; pk.z = h.pos[2]; pk.key = cell_key(ld3(h.pos), g.inv_cs);
+    hp_pos[s] = pk;
+    hp_nr[s] = make_float4(h.n[0], h.n[1], h.n[2], (float)SPPM_INIT_R2);                  // HitPoint(): R2 = INIT_R2, Raytracer.h:65
+    hp_wgt[s] = make_float4(h.wgt[0], h.wgt[1], h.wgt[2], __int_as_float(h.pix));
+    hp_tao[s] = make_float4(0, 0, 0, __int_as_float(0));                                  // tao = 0, newN = 0
+    HpMeta m; m.v[0] = h.v[0]; m.v[1] = h.v[1]; m.v[2] = h.v[2]; m.node = h.node; m.obj = h.obj; m.N = 0;
+    hp_meta[s] = m;
+}
+
+// ------------------------------------------------------------------ pass 2: photon trace
+struct PhotonParams {
+    const DevLight* lights; int n_lights; uint32_t per_round;
+    unsigned long long first, count;          // this batch: global photon indices [first, first + count)
+    unsigned long long* next;                 // batch-relative photon counter
+    PosKey* depA; DepB* depB; unsigned long long* n_dep; unsigned long long dep_cap;
+    uint32_t* dcount; GridParams grid;
+    uint32_t rng;                             // rng_base(seed, replica * 4 + D_PHOTON)
+    DevCounters* counters;
+};
+
+// RayTracer::PhotonMap's emission loop + PhotonTrace (Raytracer.h:117-209, :220-233) on
+// persistent wavefronts: a lane that finishes its photon is refilled from the photon
+// counter, so lanes stay busy across paths of different length.  A diffuse hit appends one
+// deposit record (the reference's radius-search query) instead of searching inline.
+__global__ void __launch_bounds__(256) k_photon_trace(SceneParams sp, PhotonParams pp) {
+    SceneView S = stage_scene(sp);
+    const int lane = lane_id();
+    bool active = false, exhausted = false;
+    d3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+    float flux[3] = {0, 0, 0};
+    int dep = 0;
+    uint32_t pid = 0;
+    uint32_t ncalls = 0, nseg = 0, ndep = 0, nphot = 0;
+    for (;;) {
+        uint64_t idle = __ballot(!active);
+        if (idle && !exhausted) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(pp.next, (unsigned long long)__popcll(idle));
+            base = bcast_u64(base, 0);
+            unsigned long long my = base + (unsigned long long)__popcll(idle & lanemask_lt());
+            if (base + (unsigned long long)__popcll(idle) >= pp.count) exhausted = true;
+            if (!active && my < pp.count) {
+                unsigned long long g = pp.first + my;
+                const DevLight& L = pp.lights[(g / pp.per_round) % (unsigned long long)pp.n_lights];
+                pid = (uint32_t)g;
+                uint32_t es = rng_sub(pp.rng, pid, 0u, P_EMIT);
+                double x = 0, y = 0, z = 0;
+                for (uint32_t k = 0; k < 64; k++) {                                       // Vec3::GetUnitRandVec, Vec3.h:57-65
+                    x = rng_u01(es, 3 * k + 0) * 2.0 + -1.0;
+                    y = rng_u01(es, 3 * k + 1) * 2.0 + -1.0;
+                    z = rng_u01(es, 3 * k + 2) * 2.0 + -1.0;
+                    double m = x * x + y * y + z * z;
+                    if (!(m > 1 || m < SPPM_EPS)) break;
+                }
+                d = get_unit(mk(x, y, z));
+                o = ld3(L.pos);                                                           // Light::emit, Light.h:8-13
+                flux[0] = L.flux[0]; flux[1] = L.flux[1]; flux[2] = L.flux[2];
+                dep = 0;
+                active = true;
+                nphot++;
+            }
+        }
+        if (!__any(active)) break;
+        uint32_t sub = rng_sub(pp.rng, pid, (uint32_t)dep, P_NEWTON);
+        Hit hit = near_collide(S, active, o, d, sub, ncalls);
+        if (active) nseg++;
+        if (active && hit.obj < 0) active = false;
+        bool dp = false;
+        PosKey da; DepB db;
+        if (active) {
+            const uint32_t vertex = (uint32_t)dep;
+            dep++;
+            const DevObject& ob = S.objs[hit.obj];
+            if (ob.flags & F_DIFF) {                                                      // Raytracer.h:136-160: the gather query
+                dp = true;
+                da.x = hit.pos.x; da.y = hit.pos.y; da.z = hit.pos.z;
+                da.key = cell_key(hit.pos, pp.grid.inv_cs);
+                db.nx = (float)hit.n.x; db.ny = (float)hit.n.y; db.nz = (float)hit.n.z;
+                db.fr = flux[0]; db.fg = flux[1]; db.fb = flux[2];
+                db.bucket = key_bucket(da.key, pp.grid.mask); db.pad = 0;
+            }
+            // Obj::Roulette, Obj.h:30-45
+            double r = rng_u01(rng_sub(pp.rng, pid, vertex, P_ROULETTE), 0) * ob.allr;
+            d3 nd;
+            if (ob.diffr > r) {                                                           // DIFF, Raytracer.h:163-166
+                uint32_t ds = rng_sub(pp.rng, pid, vertex, P_DIFFUSE);
+                nd = rand_refl(hit.n, rng_u01(ds, 0), rng_u01(ds, 1));
+            } else if (ob.diffr + ob.reflr > r) {                                         // REFL, Raytracer.h:177-181
+                nd = get_unit(get_refl(d, hit.n));
+            } else {                                                                      // REFR, Raytracer.h:182-190
+                double refrn = hit.inside ? ob.refrn : 1 / ob.refrn;
+                nd = get_unit(refracted(d, hit.inside ? neg(hit.n) : hit.n, refrn));
+            }
+            flux[0] *= hit.color[0]; flux[1] *= hit.color[1]; flux[2] *= hit.color[2];
+            o = hit.pos; d = nd;
+            if (dep > SPPM_MAX_DEP) active = false;                                       // Raytracer.h:126-133
+        }
+        unsigned long long slot = wave_alloc(dp, pp.n_dep);
+        if (dp) {
+            ndep++;
+            if (slot < pp.dep_cap) {
+                pp.depA[slot] = da; pp.depB[slot] = db;
+                atomicAdd(&pp.dcount[db.bucket], 1u);
+            } else atomicOr(&pp.counters->overflow, 4u);
+        }
+    }
+    flush_counter(&pp.counters->newton_calls, ncalls);
+    flush_counter(&pp.counters->segments, nseg);
+    flush_counter(&pp.counters->deposits, ndep);
+    flush_counter(&pp.counters->photons, nphot);
+}
+
+__global__ void k_dep_scatter(const PosKey* depA, const DepB* depB, const unsigned long long* n_dep, unsigned long long cap,
+                              const uint32_t* start, uint32_t* cursor, PosKey* sA, DepB* sB) {
+    unsigned long long n = min(*n_dep, cap);
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        DepB b = depB[i];
+        uint32_t s = start[b.bucket] + atomicAdd(&cursor[b.bucket], 1u);
+        sA[s] = depA[i];
+        sB[s] = b;
+    }
+}
+
+// ------------------------------------------------------------------ gather
+// The radius search + HitPoint update of Raytracer.h:146-159, turned around: HitPoints own
+// the accumulation.  One wave owns a tile of 64 grid-sorted HitPoints; for each of them the
+// lanes stream the deposits of the 27 neighbouring cells (contiguous after the sort) and apply
+//   dist^2 < searchR2  &&  hp.n . N > 1e-3  &&  dist^2 <= hp.R2   ->   newN++, tao += wgt * flux * PI_INV
+// per lane, then the wave reduces and the owner lane adds the sum to its HitPoint.
+__global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
+                                                const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
+                                                const uint32_t* __restrict__ dstart, const PosKey* __restrict__ dA,
+                                                const DepB* __restrict__ dB, GridParams g, DevCounters* counters) {
+    const int lane = lane_id();
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t base = wave * 64u;
+    if (base >= n_hp) return;
+    const uint32_t mine = base + lane;
+    const bool valid = mine < n_hp;
+    PosKey mp = hp_pos[valid ? mine : base];
+    float4 mnr = hp_nr[valid ? mine : base];
+    float4 mw = hp_wgt[valid ? mine : base];
+    float tr = 0, tg = 0, tb = 0;
+    uint32_t tn = 0, cand = 0, acc_n = 0;
+    const int cnt = (int)min(64u, n_hp - base);
+    uint64_t prev_key = ~0ull;
+    uint32_t nb_s = 0, nb_e = 0;
+    uint64_t nb_key = 0;
+    for (int j = 0; j < cnt; j++) {
+        const double hx = bcast_d(mp.x, j), hy = bcast_d(mp.y, j), hz = bcast_d(mp.z, j);
+        const uint64_t hkey = bcast_u64(mp.key, j);
+        const float nx = bcast_f(mnr.x, j), ny = bcast_f(mnr.y, j), nz = bcast_f(mnr.z, j), R2 = bcast_f(mnr.w, j);
+        const float wr = bcast_f(mw.x, j), wg = bcast_f(mw.y, j), wb = bcast_f(mw.z, j);
+        if (hkey != prev_key) {   // lanes 0..26 look up the deposit ranges of the 27 neighbour cells
+            prev_key = hkey;
+            nb_s = nb_e = 0; nb_key = 0;
+            if (lane < 27) {
+                int dx = lane % 3 - 1, dy = (lane / 3) % 3 - 1, dz = lane / 9 - 1;
+                nb_key = hkey + ((uint64_t)(int64_t)dx << 42) + ((uint64_t)(int64_t)dy << 21) + (uint64_t)(int64_t)dz;
+                uint32_t b = key_bucket(nb_key, g.mask);
+                nb_s = dstart[b]; nb_e = dstart[b + 1];
+            }
+        }
+        float pr = 0, pg = 0, pb = 0;
+        uint32_t pn = 0;
+        uint64_t nonempty = __ballot(nb_e > nb_s);
+        while (nonempty) {
+            int k = __ffsll((unsigned long long)nonempty) - 1;
+            nonempty &= nonempty - 1;
+            const uint32_t s = bcast_u(nb_s, k), e = bcast_u(nb_e, k);
+            const uint64_t key = bcast_u64(nb_key, k);
+            for (uint32_t i = s + lane; i < e; i += 64) {
+                const PosKey a = dA[i];
+                if (a.key != key) continue;   // another cell hashed into this bucket
+                const double vx = hx - a.x, vy = hy - a.y, vz = hz - a.z;
+                const double d2 = vx * vx + vy * vy + vz * vz;
+                if (d2 < SPPM_INIT_R2) {      // flann radiusSearch(radius = searchR2): strict '<' on the squared distance
+                    cand++;
+                    const DepB b = dB[i];
+                    if ((nx * b.nx + ny * b.ny + nz * b.nz > 1e-3f) && (d2 <= (double)R2)) {
+                        pn++;
+                        pr += (wr * b.fr) * (float)SPPM_PI_INV;
+                        pg += (wg * b.fg) * (float)SPPM_PI_INV;
+                        pb += (wb * b.fb) * (float)SPPM_PI_INV;
+                    }
+                }
+            }
+        }
+        if (__any(pn != 0)) {
+            pr = wave_sum_f(pr); pg = wave_sum_f(pg); pb = wave_sum_f(pb);
+            pn = wave_sum_u(pn);
+            if (lane == j) { tr += pr; tg += pg; tb += pb; tn += pn; }
+            if (lane == 0) acc_n += pn;
+        }
+    }
+    if (valid && tn) {
+        float4 t = hp_tao[mine];
+        t.x += tr; t.y += tg; t.z += tb;
+        t.w = __int_as_float(__float_as_int(t.w) + (int)tn);
+        hp_tao[mine] = t;
+    }
+    flush_counter(&counters->candidates, cand);
+    flush_counter(&counters->accepted, acc_n);
+}
+
+// ------------------------------------------------------------------ resolve (Raytracer.h:281-293)
+__global__ void k_resolve(const float4* hp_nr, const float4* hp_wgt, const float4* hp_tao, uint32_t n_hp, double inv_norm, float* pic) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_hp) return;
+    float4 t = hp_tao[i];
+    int pix = __float_as_int(hp_wgt[i].w);
+    double s = inv_norm / (double)hp_nr[i].w;   // 1 / PI / (R2 * cnt * onetime)
+    atomicAdd(&pic[3 * (size_t)pix + 0], (float)(t.x * s));
+    atomicAdd(&pic[3 * (size_t)pix + 1], (float)(t.y * s));
+    atomicAdd(&pic[3 * (size_t)pix + 2], (float)(t.z * s));
+}
+
+__global__ void k_fill_u32(uint32_t* p, size_t n, uint32_t v) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// ------------------------------------------------------------------ parity hooks
+__global__ void __launch_bounds__(256) k_debug_near_collide(SceneParams sp, uint32_t n, const double* org, const double* dir, uint32_t rng,
+                                                            sppm_collision* out, DevCounters* counters) {
+    SceneView S = stage_scene(sp);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < n;
+    d3 o = active ? ld3(org + 3 * (size_t)i) : mk(0, 0, 0), d = active ? ld3(dir + 3 * (size_t)i) : mk(0, 0, 1);
+    uint32_t ncalls = 0;
+    Hit h = near_collide(S, active, o, d, rng_sub(rng, i, 0u, P_NEWTON), ncalls);
+    if (active) {
+        sppm_collision c;
+        c.pos[0] = h.pos.x; c.pos[1] = h.pos.y; c.pos[2] = h.pos.z;
+        c.n[0] = h.n.x; c.n[1] = h.n.y; c.n[2] = h.n.z;
+        c.color[0] = h.color[0]; c.color[1] = h.color[1]; c.color[2] = h.color[2];
+        c.dist = h.obj >= 0 ? h.dist : 0.0;
+        c.obj = h.obj; c.inside = h.inside;
+        out[i] = c;
+    }
+    flush_counter(&counters->newton_calls, ncalls);
+}
+
+__global__ void __launch_bounds__(256) k_debug_newton(SceneParams sp, uint32_t n, const double* org, const double* dir, const int* patch,
+                                                      uint32_t rng, double* out_tuv) {
+    SceneView S = stage_scene(sp);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < n;
+    const int lane = lane_id();
+    double ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1;
+    int p = 0;
+    if (active) {
+        ox = org[3 * (size_t)i]; oy = org[3 * (size_t)i + 1]; oz = org[3 * (size_t)i + 2];
+        dx = dir[3 * (size_t)i]; dy = dir[3 * (size_t)i + 1]; dz = dir[3 * (size_t)i + 2];
+        p = patch[i];
+    }
+    uint32_t sub = rng_sub(rng, i, 0u, P_NEWTON);
+    float mt = (float)SPPM_MAX_NUM, mu = (float)SPPM_MAX_NUM, mv = (float)SPPM_MAX_NUM;
+    uint64_t m = __ballot(active);
+    while (m) {
+        int src = __ffsll((unsigned long long)m) - 1;
+        m &= m - 1;
+        f3 fo = {(float)bcast_d(ox, src), (float)bcast_d(oy, src), (float)bcast_d(oz, src)};
+        f3 fd = {(float)bcast_d(dx, src), (float)bcast_d(dy, src), (float)bcast_d(dz, src)};
+        float t, u, v;
+        newton_coop(S.patch_cp, bcast_i(p, src), fo, fd, bcast_u(sub, src), t, u, v);
+        if (lane == src && t < (float)SPPM_MAX_NUM) { mt = t; mu = u; mv = v; }
+    }
+    if (active) {
+        const bool none = !(mt < (float)SPPM_MAX_NUM);
+        out_tuv[3 * (size_t)i + 0] = none ? SPPM_MAX_NUM : (double)mt;
+        out_tuv[3 * (size_t)i + 1] = none ? SPPM_MAX_NUM : (double)mu;
+        out_tuv[3 * (size_t)i + 2] = none ? SPPM_MAX_NUM : (double)mv;
+    }
+}
+
+// =================================================================== host side
+namespace {
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t reserve(size_t want) {
+        if (want <= n) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e == hipSuccess) n = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+uint32_t next_pow2(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+
+}  // namespace
+
+struct sppm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // scene
+    bool have_scene = false;
+    DevBuf<char> blob; int blob_bytes = 0, off_box = 0, off_cp = 0, n_objs = 0, n_patches = 0;
+    DevBuf<TexDesc> tex; DevBuf<uchar4> texels;
+    DevBuf<DevLight> lights; int n_lights = 0;
+    // eye pass
+    bool have_eye = false;
+    sppm_camera cam{};
+    DevBuf<RawHit> raw; DevBuf<EyeTask> tasks[2];
+    DevBuf<uint32_t> bucket_of, hcount, hstart, cursor;
+    DevBuf<PosKey> hp_pos; DevBuf<float4> hp_nr, hp_wgt, hp_tao; DevBuf<HpMeta> hp_meta;
+    uint64_t n_hp = 0;
+    GridParams grid{};
+    // photon pass
+    DevBuf<PosKey> depA, sdepA; DevBuf<DepB> depB, sdepB;
+    DevBuf<uint32_t> dcount, dstart;
+    DevBuf<unsigned long long> scalars;   // [0] n_hits, [1] n_tasks_out, [2] next photon, [3] n_dep
+    DevBuf<DevCounters> counters;
+    DevBuf<float> pic;
+    uint64_t last_rounds = 0, last_per_round = 0;
+    uint64_t batch = 1u << 20;
+    sppm_timings tm{};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int num_cu = 256;
+
+    SceneParams scene_params() const {
+        SceneParams sp;
+        sp.blob = blob.p; sp.blob_bytes = blob_bytes; sp.off_box = off_box; sp.off_cp = off_cp;
+        sp.n_objs = n_objs; sp.n_patches = n_patches; sp.tex = tex.p; sp.texels = texels.p;
+        return sp;
+    }
+};
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
+            return SPPM_E_DEVICE;                                                            \
+        }                                                                                    \
+    } while (0)
+
+static int fail(sppm_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+// same mixing as rng_base() on the device
+static uint32_t host_rng_base(uint64_t seed, uint32_t stream) {
+    auto rotl = [](uint32_t x, int r) { return (x << r) | (x >> (32 - r)); };
+    auto mm = [&](uint32_t h, uint32_t k) { k *= 0xcc9e2d51u; k = rotl(k, 15); k *= 0x1b873593u; h ^= k; h = rotl(h, 13); return h * 5u + 0xe6546b64u; };
+    uint32_t h = 0x9747b28cu;
+    h = mm(h, (uint32_t)seed); h = mm(h, (uint32_t)(seed >> 32)); h = mm(h, stream);
+    return h;
+}
+
+static void tic(sppm_ctx* ctx) { (void)hipEventRecord(ctx->ev[0], ctx->stream); }
+static double toc(sppm_ctx* ctx) {
+    (void)hipEventRecord(ctx->ev[1], ctx->stream);
+    (void)hipEventSynchronize(ctx->ev[1]);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
+    return (double)ms;
+}
+
+extern "C" {
+
+int sppm_create(sppm_ctx** out, int device_id) {
+    if (!out) return SPPM_E_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return SPPM_E_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return SPPM_E_DEVICE;
+    sppm_ctx* ctx = new (std::nothrow) sppm_ctx();
+    if (!ctx) return SPPM_E_NOMEM;
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+    if (hipStreamCreate(&ctx->stream) != hipSuccess || hipEventCreate(&ctx->ev[0]) != hipSuccess ||
+        hipEventCreate(&ctx->ev[1]) != hipSuccess) {
+        delete ctx;
+        return SPPM_E_DEVICE;
+    }
+    if (const char* b = getenv("SPPM_BATCH")) {
+        long long v = atoll(b);
+        if (v > 0) ctx->batch = (uint64_t)v;
+    }
+    if (ctx->scalars.reserve(8) != hipSuccess || ctx->counters.reserve(1) != hipSuccess) {
+        delete ctx;
+        return SPPM_E_DEVICE;
+    }
+    (void)hipMemset(ctx->counters.p, 0, sizeof(DevCounters));
+    *out = ctx;
+    return SPPM_OK;
+}
+
+void sppm_destroy(sppm_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->blob.release(); ctx->tex.release(); ctx->texels.release(); ctx->lights.release();
+    ctx->raw.release(); ctx->tasks[0].release(); ctx->tasks[1].release();
+    ctx->bucket_of.release(); ctx->hcount.release(); ctx->hstart.release(); ctx->cursor.release();
+    ctx->hp_pos.release(); ctx->hp_nr.release(); ctx->hp_wgt.release(); ctx->hp_tao.release(); ctx->hp_meta.release();
+    ctx->depA.release(); ctx->sdepA.release(); ctx->depB.release(); ctx->sdepB.release();
+    ctx->dcount.release(); ctx->dstart.release(); ctx->scalars.release(); ctx->counters.release(); ctx->pic.release();
+    if (ctx->ev[0]) (void)hipEventDestroy(ctx->ev[0]);
+    if (ctx->ev[1]) (void)hipEventDestroy(ctx->ev[1]);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* sppm_last_error(const sppm_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+static bool any_zero3(const double* v) { return std::fabs(v[0]) < 1e-4 || std::fabs(v[1]) < 1e-4 || std::fabs(v[2]) < 1e-4; }
+
+int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
+    if (!ctx || !s) return SPPM_E_INVALID;
+    if (s->n_objects <= 0 || !s->objects) return fail(ctx, SPPM_E_INVALID, "scene has no objects");
+    if (s->n_lights <= 0 || !s->lights) return fail(ctx, SPPM_E_INVALID, "scene has no lights");
+    if (s->n_patches < 0 || (s->n_patches > 0 && !s->patches)) return fail(ctx, SPPM_E_INVALID, "bad patch array");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int no = s->n_objects, np = s->n_patches;
+    const int off_box = (int)(((size_t)no * sizeof(DevObject) + 15) & ~(size_t)15);
+    const int off_cp = off_box + np * 6 * (int)sizeof(double);
+    const int bytes = off_cp + np * 48 * (int)sizeof(float);
+    if (bytes > 64 * 1024) return fail(ctx, SPPM_E_CAPACITY, "scene tables exceed the 64 KiB LDS staging area (too many patches/objects)");
+    std::vector<char> blob((size_t)bytes, 0);
+    DevObject* objs = (DevObject*)blob.data();
+    double* box = (double*)(blob.data() + off_box);
+    float* cp = (float*)(blob.data() + off_cp);
+    for (int p = 0; p < np; p++) {                                                       // Bezier3::read, Bezier.h:167-175
+        double* b = box + 6 * p;
+        for (int k = 0; k < 3; k++) { b[k] = 1e20; b[3 + k] = -1e20; }
+        for (int k = 0; k < 16; k++)
+            for (int c = 0; c < 3; c++) {
+                double v = s->patches[(size_t)p * 48 + k * 3 + c];
+                cp[(size_t)p * 48 + k * 3 + c] = (float)v;
+                if (b[c] > v) b[c] = v;
+                if (b[3 + c] < v) b[3 + c] = v;
+            }
+    }
+    for (int i = 0; i < no; i++) {
+        const sppm_object& so = s->objects[i];
+        DevObject& o = objs[i];
+        if (so.type < SPPM_OBJ_PLANE || so.type > SPPM_OBJ_BEZIER) return fail(ctx, SPPM_E_INVALID, "unknown object type");
+        if (so.texture >= s->n_textures) return fail(ctx, SPPM_E_INVALID, "texture index out of range");
+        o.type = so.type; o.texture = so.texture < 0 ? -1 : so.texture;
+        for (int k = 0; k < 3; k++) {
+            o.p0[k] = so.p0[k]; o.n[k] = so.n[k];
+            o.color[k] = (float)so.color[k];
+            o.diff[k] = (float)so.material.diff[k]; o.refl[k] = (float)so.material.refl[k]; o.refr[k] = (float)so.material.refr[k];
+            o.bmin[k] = 1e20; o.bmax[k] = -1e20;
+        }
+        o.radius = so.radius; o.refrn = so.material.refrn;
+        o.diffr = (so.material.diff[0] + so.material.diff[1] + so.material.diff[2]) / 3;  // Obj.h:11-16, Vec3.h:116-119
+        o.reflr = (so.material.refl[0] + so.material.refl[1] + so.material.refl[2]) / 3;
+        o.refrr = (so.material.refr[0] + so.material.refr[1] + so.material.refr[2]) / 3;
+        o.allr = o.diffr + o.reflr + o.refrr;
+        // Material::IsDiff etc.: !IsZero(vec), where IsZero(vec) is true if ANY component is ~0 (Element.h:16-18, Vec3.h:72-79)
+        o.flags = (any_zero3(so.material.diff) ? 0 : F_DIFF) | (any_zero3(so.material.refl) ? 0 : F_REFL) |
+                  (any_zero3(so.material.refr) ? 0 : F_REFR);
+        o.first_patch = so.first_patch; o.n_patches = so.n_patches; o.pad = 0;
+        if (so.type == SPPM_OBJ_BEZIER) {
+            if (so.first_patch < 0 || so.n_patches < 0 || so.first_patch + so.n_patches > np)
+                return fail(ctx, SPPM_E_INVALID, "bezier object indexes patches out of range");
+            for (int p = so.first_patch; p < so.first_patch + so.n_patches; p++)           // Bezier.h:226-231
+                for (int k = 0; k < 3; k++) {
+                    o.bmin[k] = std::min(o.bmin[k], box[6 * p + k]);
+                    o.bmax[k] = std::max(o.bmax[k], box[6 * p + 3 + k]);
+                }
+        }
+    }
+    HIPCHK(ctx->blob.reserve((size_t)bytes));
+    HIPCHK(hipMemcpy(ctx->blob.p, blob.data(), (size_t)bytes, hipMemcpyHostToDevice));
+    ctx->blob_bytes = bytes; ctx->off_box = off_box; ctx->off_cp = off_cp; ctx->n_objs = no; ctx->n_patches = np;
+    // textures -> packed uchar4
+    std::vector<TexDesc> td((size_t)std::max(1, s->n_textures));
+    size_t total = 0;
+    for (int t = 0; t < s->n_textures; t++) {
+        if (s->textures[t].rows <= 0 || s->textures[t].cols <= 0 || !s->textures[t].texels)
+            return fail(ctx, SPPM_E_INVALID, "empty texture");
+        td[t].rows = s->textures[t].rows; td[t].cols = s->textures[t].cols; td[t].offset = (unsigned)total; td[t].pad = 0;
+        total += (size_t)td[t].rows * td[t].cols;
+    }
+    std::vector<uchar4> tx(std::max<size_t>(1, total));
+    for (int t = 0; t < s->n_textures; t++) {
+        const uint8_t* src = s->textures[t].texels;
+        uchar4* dst = tx.data() + td[t].offset;
+        for (size_t k = 0; k < (size_t)td[t].rows * td[t].cols; k++) dst[k] = make_uchar4(src[3 * k], src[3 * k + 1], src[3 * k + 2], 0);
+    }
+    HIPCHK(ctx->tex.reserve(td.size()));
+    HIPCHK(hipMemcpy(ctx->tex.p, td.data(), td.size() * sizeof(TexDesc), hipMemcpyHostToDevice));
+    HIPCHK(ctx->texels.reserve(tx.size()));
+    HIPCHK(hipMemcpy(ctx->texels.p, tx.data(), tx.size() * sizeof(uchar4), hipMemcpyHostToDevice));
+    std::vector<DevLight> dl((size_t)s->n_lights);
+    for (int l = 0; l < s->n_lights; l++)
+        for (int k = 0; k < 3; k++) {
+            dl[l].pos[k] = s->lights[l].pos[k];
+            dl[l].flux[k] = (float)(s->lights[l].color[k] * SPPM_PI * 4);                  // Light.h:10
+        }
+    HIPCHK(ctx->lights.reserve(dl.size()));
+    HIPCHK(hipMemcpy(ctx->lights.p, dl.data(), dl.size() * sizeof(DevLight), hipMemcpyHostToDevice));
+    ctx->n_lights = s->n_lights;
+    ctx->have_scene = true;
+    ctx->have_eye = false;
+    return SPPM_OK;
+}
+
+static int launch_fill(sppm_ctx* ctx, uint32_t* p, size_t n, uint32_t v) {
+    if (n == 0) return SPPM_OK;
+    int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, ctx->stream, p, n, v);
+    HIPCHK(hipGetLastError());
+    return SPPM_OK;
+}
+
+int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t replica) {
+    if (!ctx || !cam) return SPPM_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, SPPM_E_INVALID, "sppm_set_scene must come first");
+    if (cam->w <= 0 || cam->h <= 0 || (uint64_t)cam->w * cam->h > (1ull << 30)) return fail(ctx, SPPM_E_INVALID, "bad resolution");
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->cam = *cam;
+    ctx->have_eye = false;
+    const uint64_t npx = (uint64_t)cam->w * cam->h;
+    uint64_t hit_cap = std::max<uint64_t>(2 * npx, 1 << 16);
+    uint64_t task_cap = std::max<uint64_t>(npx, 1 << 16);
+    SceneParams sp = ctx->scene_params();
+    ctx->tm = sppm_timings{};
+    for (int attempt = 0; attempt < 6; attempt++) {
+        HIPCHK(ctx->raw.reserve(hit_cap));
+        HIPCHK(ctx->tasks[0].reserve(task_cap));
+        HIPCHK(ctx->tasks[1].reserve(task_cap));
+        HIPCHK(hipMemsetAsync(ctx->scalars.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->counters.p, 0, sizeof(DevCounters), ctx->stream));
+        tic(ctx);
+        EyeParams ep;
+        for (int k = 0; k < 3; k++) { ep.pos[k] = cam->pos[k]; ep.dir[k] = cam->dir[k]; ep.du[k] = cam->du[k]; ep.dv[k] = cam->dv[k]; }
+        ep.w = cam->w; ep.h = cam->h;
+        ep.hits = ctx->raw.p; ep.n_hits = ctx->scalars.p + 0; ep.hit_cap = hit_cap;
+        ep.n_tasks_out = ctx->scalars.p + 1; ep.task_cap = task_cap;
+        ep.counters = ctx->counters.p;
+        ep.rng = host_rng_base(seed, replica * 4u + D_EYE);
+        uint64_t n_tasks = npx;
+        const EyeTask* in = nullptr;
+        int cur = 0, launches = 0;
+        bool overflow = false;
+        while (n_tasks > 0) {
+            ep.n_tasks = (int)n_tasks; ep.tasks_in = in; ep.tasks_out = ctx->tasks[cur].p;
+            HIPCHK(hipMemsetAsync(ctx->scalars.p + 1, 0, sizeof(unsigned long long), ctx->stream));
+            int blocks = (int)((n_tasks + 255) / 256);
+            hipLaunchKernelGGL(k_eye_trace, dim3(blocks), dim3(256), (size_t)ctx->blob_bytes, ctx->stream, sp, ep);
+            HIPCHK(hipGetLastError());
+            launches++;
+            unsigned long long sc[2];
+            HIPCHK(hipMemcpyAsync(sc, ctx->scalars.p, sizeof(sc), hipMemcpyDeviceToHost, ctx->stream));
+            DevCounters dc;
+            HIPCHK(hipMemcpyAsync(&dc, ctx->counters.p, sizeof(dc), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (dc.overflow) { overflow = true; break; }
+            n_tasks = sc[1];
+            in = ctx->tasks[cur].p;
+            cur ^= 1;
+            ctx->n_hp = sc[0];
+        }
+        ctx->tm.eye_trace_ms = toc(ctx);
+        ctx->tm.trace_launches = launches;
+        if (!overflow) break;
+        if (attempt == 5) return fail(ctx, SPPM_E_CAPACITY, "eye pass queues overflowed after 5 capacity doublings");
+        hit_cap *= 2; task_cap *= 2;
+    }
+    // ---- hashed grid over HitPoints
+    const uint64_t n = ctx->n_hp;
+    const double cs = std::sqrt(SPPM_INIT_R2) * 1.0001;   // cell >= search radius: neighbours within +-1 cell
+    ctx->grid.inv_cs = 1.0 / cs;
+    const uint32_t M = std::min<uint32_t>(1u << 22, std::max<uint32_t>(1u << 16, next_pow2(2 * std::max<uint64_t>(n, 1))));
+    ctx->grid.mask = M - 1;
+    tic(ctx);
+    HIPCHK(ctx->bucket_of.reserve(std::max<uint64_t>(n, 1)));
+    HIPCHK(ctx->hcount.reserve(M + 1)); HIPCHK(ctx->hstart.reserve(M + 1)); HIPCHK(ctx->cursor.reserve(M + 1));
+    HIPCHK(ctx->dcount.reserve(M + 1)); HIPCHK(ctx->dstart.reserve(M + 1));
+    HIPCHK(ctx->hp_pos.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_nr.reserve(std::max<uint64_t>(n, 1)));
+    HIPCHK(ctx->hp_wgt.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_tao.reserve(std::max<uint64_t>(n, 1)));
+    HIPCHK(ctx->hp_meta.reserve(std::max<uint64_t>(n, 1)));
+    if (int rc = launch_fill(ctx, ctx->hcount.p, M + 1, 0)) return rc;
+    if (int rc = launch_fill(ctx, ctx->cursor.p, M + 1, 0)) return rc;
+    if (n > 0) {
+        const int blocks = (int)((n + 255) / 256);
+        hipLaunchKernelGGL(k_hp_count, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)n, ctx->grid, ctx->bucket_of.p, ctx->hcount.p);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->hcount.p, ctx->hstart.p, M);
+        hipLaunchKernelGGL(k_hp_scatter, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)n, ctx->grid, ctx->bucket_of.p,
+                           ctx->hstart.p, ctx->cursor.p, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->hp_tao.p, ctx->hp_meta.p);
+        HIPCHK(hipGetLastError());
+    }
+    ctx->tm.grid_build_ms = toc(ctx);
+    ctx->have_eye = true;
+    ctx->last_rounds = 0; ctx->last_per_round = 0;
+    return SPPM_OK;
+}
+
+int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_t photon_begin, uint64_t photon_count,
+                     uint64_t seed, uint32_t replica) {
+    if (!ctx) return SPPM_E_INVALID;
+    if (!ctx->have_eye) return fail(ctx, SPPM_E_INVALID, "sppm_eye_pass must come first");
+    if (rounds == 0 || per_round == 0) return fail(ctx, SPPM_E_INVALID, "rounds and per_round must be positive");
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t total = rounds * (uint64_t)ctx->n_lights * per_round;
+    if (total > 0xffffffffull) return fail(ctx, SPPM_E_INVALID, "more than 2^32 photons in one pass");
+    if (photon_begin > total) return fail(ctx, SPPM_E_INVALID, "photon_begin beyond the pass");
+    const uint64_t end = photon_count == 0 ? total : std::min(total, photon_begin + photon_count);
+    ctx->last_rounds = rounds; ctx->last_per_round = per_round;
+    const uint32_t M = ctx->grid.mask + 1;
+    SceneParams sp = ctx->scene_params();
+    PhotonParams pp;
+    pp.lights = ctx->lights.p; pp.n_lights = ctx->n_lights; pp.per_round = per_round;
+    pp.next = ctx->scalars.p + 2; pp.n_dep = ctx->scalars.p + 3;
+    pp.dcount = ctx->dcount.p; pp.grid = ctx->grid; pp.counters = ctx->counters.p;
+    pp.rng = host_rng_base(seed, replica * 4u + D_PHOTON);
+    const uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(ctx->batch, end > photon_begin ? end - photon_begin : 1));
+    const uint64_t dep_cap = batch * (SPPM_MAX_DEP + 1);
+    HIPCHK(ctx->depA.reserve(dep_cap)); HIPCHK(ctx->depB.reserve(dep_cap));
+    HIPCHK(ctx->sdepA.reserve(dep_cap)); HIPCHK(ctx->sdepB.reserve(dep_cap));
+    pp.depA = ctx->depA.p; pp.depB = ctx->depB.p; pp.dep_cap = dep_cap;
+    const int trace_blocks = ctx->num_cu * 4;
+    ctx->tm.photon_trace_ms = ctx->tm.deposit_sort_ms = ctx->tm.gather_ms = 0;
+    ctx->tm.gather_launches = 0;
+    for (uint64_t first = photon_begin; first < end; first += batch) {
+        const uint64_t count = std::min(batch, end - first);
+        pp.first = first; pp.count = count;
+        HIPCHK(hipMemsetAsync(ctx->scalars.p + 2, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        if (int rc = launch_fill(ctx, ctx->dcount.p, M + 1, 0)) return rc;
+        if (int rc = launch_fill(ctx, ctx->cursor.p, M + 1, 0)) return rc;
+        tic(ctx);
+        hipLaunchKernelGGL(k_photon_trace, dim3(trace_blocks), dim3(256), (size_t)ctx->blob_bytes, ctx->stream, sp, pp);
+        HIPCHK(hipGetLastError());
+        ctx->tm.photon_trace_ms += toc(ctx);
+        tic(ctx);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->dcount.p, ctx->dstart.p, M);
+        hipLaunchKernelGGL(k_dep_scatter, dim3(ctx->num_cu * 8), dim3(256), 0, ctx->stream, ctx->depA.p, ctx->depB.p, ctx->scalars.p + 3,
+                           dep_cap, ctx->dstart.p, ctx->cursor.p, ctx->sdepA.p, ctx->sdepB.p);
+        HIPCHK(hipGetLastError());
+        ctx->tm.deposit_sort_ms += toc(ctx);
+        if (ctx->n_hp > 0) {
+            tic(ctx);
+            const int waves = (int)((ctx->n_hp + 63) / 64);
+            const int blocks = (waves + 3) / 4;
+            hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->hp_tao.p,
+                               (uint32_t)ctx->n_hp, ctx->dstart.p, ctx->sdepA.p, ctx->sdepB.p, ctx->grid, ctx->counters.p);
+            HIPCHK(hipGetLastError());
+            ctx->tm.gather_ms += toc(ctx);
+            ctx->tm.gather_launches++;
+        }
+    }
+    DevCounters dc;
+    HIPCHK(hipMemcpyAsync(&dc, ctx->counters.p, sizeof(dc), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (dc.overflow & 4u) return fail(ctx, SPPM_E_CAPACITY, "deposit queue overflowed");
+    return SPPM_OK;
+}
+
+int sppm_resolve_device(sppm_ctx* ctx, float* dev_pic) {
+    if (!ctx || !dev_pic) return SPPM_E_INVALID;
+    if (!ctx->have_eye) return fail(ctx, SPPM_E_INVALID, "sppm_eye_pass must come first");
+    if (ctx->last_rounds == 0) return fail(ctx, SPPM_E_INVALID, "sppm_photon_pass must come first");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t npx = (size_t)ctx->cam.w * ctx->cam.h;
+    tic(ctx);
+    HIPCHK(hipMemsetAsync(dev_pic, 0, npx * 3 * sizeof(float), ctx->stream));
+    if (ctx->n_hp > 0) {
+        const double inv_norm = 1.0 / SPPM_PI / ((double)ctx->last_rounds * (double)ctx->last_per_round);
+        const int blocks = (int)((ctx->n_hp + 255) / 256);
+        hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->hp_tao.p, (uint32_t)ctx->n_hp,
+                           inv_norm, dev_pic);
+        HIPCHK(hipGetLastError());
+    }
+    ctx->tm.resolve_ms = toc(ctx);
+    return SPPM_OK;
+}
+
+int sppm_resolve(sppm_ctx* ctx, double* pic, int accumulate) {
+    if (!ctx || !pic) return SPPM_E_INVALID;
+    if (!ctx->have_eye) return fail(ctx, SPPM_E_INVALID, "sppm_eye_pass must come first");
+    const size_t n = (size_t)ctx->cam.w * ctx->cam.h * 3;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(ctx->pic.reserve(n));
+    if (int rc = sppm_resolve_device(ctx, ctx->pic.p)) return rc;
+    std::vector<float> h(n);
+    HIPCHK(hipMemcpyAsync(h.data(), ctx->pic.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (accumulate) for (size_t i = 0; i < n; i++) pic[i] += (double)h[i];
+    else for (size_t i = 0; i < n; i++) pic[i] = (double)h[i];
+    return SPPM_OK;
+}
+
+int sppm_get_hitpoints(sppm_ctx* ctx, sppm_hitpoint* out, uint64_t cap, uint64_t* n) {
+    if (!ctx || !n) return SPPM_E_INVALID;
+    if (!ctx->have_eye) return fail(ctx, SPPM_E_INVALID, "sppm_eye_pass must come first");
+    *n = ctx->n_hp;
+    const uint64_t m = std::min<uint64_t>(cap, ctx->n_hp);
+    if (m == 0 || !out) return SPPM_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<PosKey> pos(m); std::vector<float4> nr(m), wg(m), tao(m); std::vector<HpMeta> meta(m);
+    HIPCHK(hipMemcpy(pos.data(), ctx->hp_pos.p, m * sizeof(PosKey), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(nr.data(), ctx->hp_nr.p, m * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(wg.data(), ctx->hp_wgt.p, m * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tao.data(), ctx->hp_tao.p, m * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(meta.data(), ctx->hp_meta.p, m * sizeof(HpMeta), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < m; i++) {
+        sppm_hitpoint& h = out[i];
+        h.pos[0] = pos[i].x; h.pos[1] = pos[i].y; h.pos[2] = pos[i].z;
+        h.n[0] = nr[i].x; h.n[1] = nr[i].y; h.n[2] = nr[i].z; h.R2 = nr[i].w;
+        h.v[0] = meta[i].v[0]; h.v[1] = meta[i].v[1]; h.v[2] = meta[i].v[2];
+        h.wgt[0] = wg[i].x; h.wgt[1] = wg[i].y; h.wgt[2] = wg[i].z;
+        h.tao[0] = tao[i].x; h.tao[1] = tao[i].y; h.tao[2] = tao[i].z;
+        int pix, newN;
+        memcpy(&pix, &wg[i].w, 4); memcpy(&newN, &tao[i].w, 4);
+        h.x = pix / ctx->cam.w; h.y = pix % ctx->cam.w;
+        h.obj = meta[i].obj; h.node = meta[i].node; h.N = meta[i].N; h.newN = newN;
+    }
+    return SPPM_OK;
+}
+
+int sppm_get_counters(sppm_ctx* ctx, sppm_counters* out) {
+    if (!ctx || !out) return SPPM_E_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    DevCounters dc;
+    HIPCHK(hipMemcpy(&dc, ctx->counters.p, sizeof(dc), hipMemcpyDeviceToHost));
+    out->photons = dc.photons; out->segments = dc.segments; out->deposits = dc.deposits;
+    out->candidates = dc.candidates; out->accepted = dc.accepted; out->hitpoints = ctx->n_hp;
+    out->newton_calls = dc.newton_calls; out->eye_segments = dc.eye_segments;
+    return SPPM_OK;
+}
+
+int sppm_get_timings(sppm_ctx* ctx, sppm_timings* out) {
+    if (!ctx || !out) return SPPM_E_INVALID;
+    *out = ctx->tm;
+    return SPPM_OK;
+}
+
+int sppm_debug_near_collide(sppm_ctx* ctx, uint64_t n, const double* org, const double* dir, uint64_t seed, uint32_t replica,
+                            sppm_collision* out) {
+    if (!ctx || !org || !dir || !out) return SPPM_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, SPPM_E_INVALID, "sppm_set_scene must come first");
+    if (n == 0) return SPPM_OK;
+    if (n > (1u << 28)) return fail(ctx, SPPM_E_INVALID, "too many rays");
+    HIPCHK(hipSetDevice(ctx->device));
+    DevBuf<double> o, d; DevBuf<sppm_collision> c;
+    int rc = SPPM_OK;
+    do {
+        if (o.reserve(3 * n) != hipSuccess || d.reserve(3 * n) != hipSuccess || c.reserve(n) != hipSuccess) { rc = fail(ctx, SPPM_E_NOMEM, "hipMalloc failed"); break; }
+        (void)hipMemcpy(o.p, org, 3 * n * sizeof(double), hipMemcpyHostToDevice);
+        (void)hipMemcpy(d.p, dir, 3 * n * sizeof(double), hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_debug_near_collide, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)ctx->blob_bytes, ctx->stream,
+                           ctx->scene_params(), (uint32_t)n, o.p, d.p, host_rng_base(seed, replica * 4u + D_EYE), c.p, ctx->counters.p);
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { rc = fail(ctx, SPPM_E_DEVICE, hipGetErrorString(e)); break; }
+        (void)hipMemcpy(out, c.p, n * sizeof(sppm_collision), hipMemcpyDeviceToHost);
+    } while (0);
+    o.release(); d.release(); c.release();
+    return rc;
+}
+
+int sppm_debug_newton(sppm_ctx* ctx, uint64_t n, const double* org, const double* dir, const int32_t* patch, uint64_t seed,
+                      uint32_t replica, double* out_tuv) {
+    if (!ctx || !org || !dir || !patch || !out_tuv) return SPPM_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, SPPM_E_INVALID, "sppm_set_scene must come first");
+    if (n == 0) return SPPM_OK;
+    if (n > (1u << 28)) return fail(ctx, SPPM_E_INVALID, "too many rays");
+    for (uint64_t i = 0; i < n; i++)
+        if (patch[i] < 0 || patch[i] >= ctx->n_patches) return fail(ctx, SPPM_E_INVALID, "patch index out of range");
+    HIPCHK(hipSetDevice(ctx->device));
+    DevBuf<double> o, d, r; DevBuf<int> p;
+    int rc = SPPM_OK;
+    do {
+        if (o.reserve(3 * n) != hipSuccess || d.reserve(3 * n) != hipSuccess || r.reserve(3 * n) != hipSuccess || p.reserve(n) != hipSuccess) {
+            rc = fail(ctx, SPPM_E_NOMEM, "hipMalloc failed"); break;
+        }
+        (void)hipMemcpy(o.p, org, 3 * n * sizeof(double), hipMemcpyHostToDevice);
+        (void)hipMemcpy(d.p, dir, 3 * n * sizeof(double), hipMemcpyHostToDevice);
+        (void)hipMemcpy(p.p, patch, n * sizeof(int), hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_debug_newton, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)ctx->blob_bytes, ctx->stream,
+                           ctx->scene_params(), (uint32_t)n, o.p, d.p, p.p, host_rng_base(seed, replica * 4u + D_EYE), r.p);
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { rc = fail(ctx, SPPM_E_DEVICE, hipGetErrorString(e)); break; }
+        (void)hipMemcpy(out_tuv, r.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost);
+    } while (0);
+    o.release(); d.release(); r.release(); p.release();
+    return rc;
+}
+
+}  // extern "C"

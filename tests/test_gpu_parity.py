@@ -1,0 +1,253 @@
+"""GPU parity tests: libsppm_hip.so (through the C-ABI) against the CPU oracle on the
+same seeded inputs.
+
+Tolerances.  The device computes ray state / analytic hits / gather distances in fp64
+and the Bezier Newton solve, colours and accumulators in fp32; the oracle is all fp64
+(optionally fp32 inside Newton).  So:
+  * analytic (plane / sphere) geometry: 1e-9 absolute on positions and distances;
+  * Bezier hits: the Newton result is the minimum-t iterate with residual < 1e-2, so two
+    arithmetic types agree to ~1e-4 on most rays and differ by up to the residual
+    threshold on the few rays where a different iterate wins; stated per test;
+  * flux image: relative to the image mean, |diff| <= 1e-3 on >= 99.5 % of pixels and
+    mean-abs-error <= 1e-4 (fp32 accumulation order + discrete-decision flips).
+"""
+import numpy as np
+import pytest
+
+from raytrace3_amd import SppmContext, scenes
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20260101
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    ctx = SppmContext(0)
+    yield ctx
+    ctx.close()
+
+
+def _oracle(scene, **kw):
+    o = ol.OracleContext(**kw)
+    o.set_scene(scene)
+    return o
+
+
+def _camera_rays(cam, n, rng):
+    """n random eye rays through the image plane (continuous pixel coordinates)."""
+    du, dv, dr, pos = (np.array(list(getattr(cam, k))) for k in ("du", "dv", "dir", "pos"))
+    a, b = rng.random(n) - 0.5, rng.random(n) - 0.5
+    d = a[:, None] * du + b[:, None] * dv + dr
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.tile(pos, (n, 1)), d
+
+
+def _key(hp):
+    return (hp["x"].astype(np.int64) << 40) | (hp["y"].astype(np.int64) << 20) | hp["node"].astype(np.int64)
+
+
+def test_near_collide_analytic_scene(gpu):
+    scene = scenes.scene_spheres_plane(True)
+    gpu.set_scene(scene)
+    o = _oracle(scene)
+    rng = np.random.default_rng(1)
+    org, d = _camera_rays(scenes.default_camera(64, 64), 4096, rng)
+    # plus rays from inside the box in random directions (hits spheres from inside / behind)
+    o2 = np.tile([50., 30., 80.], (2048, 1)) + rng.normal(size=(2048, 3)) * 5
+    d2 = rng.normal(size=(2048, 3))
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    org, d = np.concatenate([org, o2]), np.concatenate([d, d2])
+    g, c = gpu.near_collide(org, d, SEED), o.near_collide(org, d, SEED)
+    assert np.array_equal(g["obj"], c["obj"])
+    assert np.array_equal(g["inside"], c["inside"])
+    hit = c["obj"] >= 0
+    assert hit.sum() > 5000
+    assert np.allclose(g["dist"][hit], c["dist"][hit], rtol=1e-12, atol=1e-9)
+    assert np.allclose(g["pos"][hit], c["pos"][hit], rtol=0, atol=1e-9)
+    assert np.allclose(g["n"][hit], c["n"][hit], rtol=0, atol=1e-12)
+    assert np.allclose(g["color"][hit], c["color"][hit], rtol=0, atol=1e-6)
+
+
+def test_textured_objects(gpu):
+    scene = scenes.scene_teapot(1, textured=True)
+    gpu.set_scene(scene)
+    o = _oracle(scene)
+    rng = np.random.default_rng(2)
+    org, d = _camera_rays(scenes.default_camera(64, 64), 8192, rng)
+    g, c = gpu.near_collide(org, d, SEED), o.near_collide(org, d, SEED)
+    analytic = (c["obj"] >= 0) & (c["obj"] != 8) & (g["obj"] == c["obj"])
+    assert analytic.sum() > 6000
+    assert np.allclose(g["color"][analytic], c["color"][analytic], rtol=0, atol=2e-6)
+    assert np.allclose(g["pos"][analytic], c["pos"][analytic], rtol=0, atol=1e-9)
+    assert len(np.unique(np.round(c["color"][analytic], 4), axis=0)) > 100   # the textures were really sampled
+
+
+def test_newton_golden_cases(gpu):
+    """256 (ray, patch) pairs aimed at teapot patches: (t,u,v) against the oracle."""
+    scene = scenes.scene_teapot(1, textured=False)
+    gpu.set_scene(scene)
+    P = scene.patches
+    rng = np.random.default_rng(3)
+    n = 256
+    patch = rng.integers(0, 32, size=n).astype(np.int32)
+    org = np.tile([50., 35., 230.], (n, 1)) + rng.normal(size=(n, 3)) * 20
+    uv = rng.random((n, 2))
+    # aim at a point of the patch's control net hull (not exactly on the surface)
+    tgt = np.array([P[p].reshape(4, 4, 3)[int(a * 3.999), int(b * 3.999)] for p, (a, b) in zip(patch, uv)])
+    d = tgt - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    g = gpu.newton(org, d, patch, SEED)
+    c32 = _oracle(scene, newton_fp32=True).newton(org, d, patch, SEED)
+    c64 = _oracle(scene).newton(org, d, patch, SEED)
+    found_c, found_g = c64[:, 0] < 1e19, g[:, 0] < 1e19
+    assert found_c.sum() > 60
+    # converged / not converged decisions agree on all but a few borderline cases
+    assert (found_c != found_g).sum() <= 3
+    both = found_c & found_g
+    err = np.abs(g[both] - c64[both]).max(axis=1)
+    assert np.median(err) < 1e-4
+    assert (err < 1e-3).mean() > 0.9, (err < 1e-3).mean()
+    assert err.max() < 0.05          # never further apart than the residual threshold allows
+    both32 = (c32[:, 0] < 1e19) & found_g
+    err32 = np.abs(g[both32] - c32[both32]).max(axis=1)
+    assert np.median(err32) < 1e-4
+
+
+def _compare_hitpoints(g, c, pos_tol, frac):
+    assert len(g) > 0
+    kg, kc = _key(g), _key(c)
+    og, oc = np.argsort(kg), np.argsort(kc)
+    g, c, kg, kc = g[og], c[oc], kg[og], kc[oc]
+    common, ig, ic = np.intersect1d(kg, kc, return_indices=True)
+    missing = (len(kg) - len(common)) + (len(kc) - len(common))
+    assert missing <= (1 - frac) * len(kc) + 2, (len(kg), len(kc), len(common))
+    g, c = g[ig], c[ic]
+    same_obj = g["obj"] == c["obj"]
+    assert same_obj.mean() >= frac
+    perr = np.abs(g["pos"] - c["pos"]).max(axis=1)[same_obj]
+    assert (perr <= pos_tol).mean() >= frac, (perr <= pos_tol).mean()
+    ok = same_obj.copy()
+    ok[same_obj] = perr <= pos_tol
+    assert np.allclose(g["wgt"][ok], c["wgt"][ok], rtol=2e-5, atol=1e-6)
+    assert np.allclose(g["n"][ok], c["n"][ok], rtol=0, atol=5e-2)
+    assert (g["R2"] == 2.0).all() and (g["N"] == 0).all()
+    return ok.mean()
+
+
+def test_eye_pass_hitpoints_analytic(gpu):
+    scene = scenes.scene_spheres_plane(True)
+    cam = scenes.default_camera(96, 64)      # non-square on purpose (Camera.h:18-22 has no aspect ratio)
+    gpu.set_scene(scene)
+    gpu.eye_pass(cam, SEED)
+    o = _oracle(scene)
+    o.eye_pass(cam, SEED)
+    g, c = gpu.hitpoints(), o.hitpoints()
+    assert len(g) == len(c)
+    assert np.array_equal(np.sort(_key(g)), np.sort(_key(c)))
+    _compare_hitpoints(g, c, 1e-9, 1.0)
+    assert gpu.counters()["eye_segments"] == o.counters()["eye_segments"]
+
+
+def test_eye_pass_hitpoints_teapot(gpu):
+    scene = scenes.scene_teapot(1)
+    cam = scenes.default_camera(64, 64)
+    gpu.set_scene(scene)
+    gpu.eye_pass(cam, SEED)
+    o = _oracle(scene)
+    o.eye_pass(cam, SEED)
+    g, c = gpu.hitpoints(), o.hitpoints()
+    ok = _compare_hitpoints(g, c, 1e-3, 0.97)
+    print("teapot hitpoints within 1e-3:", ok)
+    assert gpu.counters()["newton_calls"] == pytest.approx(o.counters()["newton_calls"], rel=0.02)
+
+
+def _image_parity(g, c, frac=0.995, linf=1e-3, mae=1e-4):
+    mean = c.mean()
+    assert mean > 0
+    diff = np.abs(g - c).max(axis=2) / mean
+    good = (diff <= linf).mean()
+    print(f"image parity: mean {mean:.5g}, within {linf:g}: {good:.5f}, MAE/mean {diff.mean():.3g}, max {diff.max():.3g}")
+    assert good >= frac, good
+    assert diff.mean() <= mae, diff.mean()
+
+
+def test_photon_pass_image_analytic(gpu):
+    scene = scenes.scene_spheres_plane(True)
+    cam = scenes.default_camera(64, 64)
+    gpu.set_scene(scene)
+    gpu.eye_pass(cam, SEED)
+    gpu.photon_pass(200, 100, SEED)
+    o = _oracle(scene)
+    o.eye_pass(cam, SEED)
+    o.photon_pass(200, 100, SEED)
+    cg, co = gpu.counters(), o.counters()
+    assert cg["photons"] == co["photons"] == 20000
+    assert cg["segments"] == pytest.approx(co["segments"], rel=1e-3)
+    assert cg["deposits"] == pytest.approx(co["deposits"], rel=1e-3)
+    assert cg["candidates"] == pytest.approx(co["candidates"], rel=1e-3)
+    assert cg["accepted"] == pytest.approx(co["accepted"], rel=1e-3)
+    _image_parity(gpu.resolve(), o.resolve())
+    hg, hc = gpu.hitpoints(), o.hitpoints()
+    assert hg["newN"].sum() == cg["accepted"]
+    og, oc = np.argsort(_key(hg)), np.argsort(_key(hc))
+    assert (hg["newN"][og] != hc["newN"][oc]).mean() < 0.005
+
+
+def test_photon_pass_image_teapot(gpu):
+    scene = scenes.scene_teapot(1)
+    cam = scenes.default_camera(48, 48)
+    gpu.set_scene(scene)
+    gpu.eye_pass(cam, SEED)
+    gpu.photon_pass(100, 100, SEED)
+    o = _oracle(scene)
+    o.eye_pass(cam, SEED)
+    o.photon_pass(100, 100, SEED)
+    cg, co = gpu.counters(), o.counters()
+    assert cg["photons"] == co["photons"]
+    assert cg["segments"] == pytest.approx(co["segments"], rel=5e-3)
+    assert cg["accepted"] == pytest.approx(co["accepted"], rel=2e-2)
+    # Bezier hits differ at the Newton residual scale, so teapot pixels and photons that touched the
+    # teapot are allowed to differ: 97 % of pixels within 1e-3 of the mean, MAE 2e-3
+    _image_parity(gpu.resolve(), o.resolve(), frac=0.97, mae=2e-3)
+
+
+def test_photon_sharding_and_batches(gpu):
+    """Two photon ranges (what two ranks would trace) sum to the whole pass; batch size is immaterial."""
+    scene = scenes.scene_spheres_plane(True)
+    cam = scenes.default_camera(32, 32)
+    gpu.set_scene(scene)
+    gpu.eye_pass(cam, SEED)
+    gpu.photon_pass(50, 100, SEED)
+    full = gpu.resolve()
+    gpu.eye_pass(cam, SEED)
+    gpu.photon_pass(50, 100, SEED, photon_begin=0, photon_count=1700)
+    a = gpu.resolve()
+    gpu.eye_pass(cam, SEED)
+    gpu.photon_pass(50, 100, SEED, photon_begin=1700, photon_count=3300)
+    b = gpu.resolve()
+    assert np.allclose(a + b, full, rtol=1e-4, atol=1e-6 * full.mean())
+    # accumulate = 1 adds into the caller's image (the replica sum of Raytracer.h:449-458)
+    acc = a.copy()
+    gpu.resolve(accumulate_into=acc)
+    assert np.allclose(acc, a + b, rtol=1e-6, atol=0)
+
+
+def test_empty_and_error_paths(gpu):
+    from raytrace3_amd import SppmError
+    fresh = SppmContext(0)
+    with pytest.raises(SppmError):
+        fresh.eye_pass(scenes.default_camera(8, 8), 1)          # no scene yet
+    scene = scenes.scene_spheres_plane(False)
+    fresh.set_scene(scene)
+    with pytest.raises(SppmError):
+        fresh.photon_pass(1, 1, 1)                               # no eye pass yet
+    # a camera looking away from everything: no HitPoints, passes still succeed
+    cam = scenes.look_at((50, 200, 230), (50, 1000, 230.5), 16, 16)
+    fresh.eye_pass(cam, 1)
+    assert len(fresh.hitpoints()) == 0
+    fresh.photon_pass(2, 100, 1)
+    assert fresh.resolve().sum() == 0
+    assert fresh.counters()["photons"] == 200
+    fresh.close()
