@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py — SPPM hot path on MI355X: Mphotons/s and ms per SPPM iteration.
+
+One step = one SPPM iteration of one replica on the teapot Cornell scene at 800x600
+(eye pass + HitPoint grid + photon pass + resolve, plus the all-reduce of the flux image
+when N > 1).  Every rank traces 1 M photons per step (rounds = 10000 x 100 per GPU,
+Raytracer.h:218,384); with N ranks the pass is N x 1 M photons of the SAME replica,
+sharded by photon index, so per-GPU work is fixed ("weak").  `value` is photons of all
+ranks / wall time of the timed steps; the photon-pass-only rate (the metric's own
+definition) is reported beside it.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (spec)
+SEED = 20260101
+
+
+def cpu_baseline(scene, w, h, rounds, threads):
+    """The reference's CPU path as restated by the oracle (fp64, global MWC stream, kd-tree
+    radius search + the per-round update() sweep), `threads` replicas in parallel like the
+    reference's `omp parallel for num_threads(4)`.  Bounded sample: full-resolution eye pass,
+    `rounds` x 100 photons per replica."""
+    from raytrace3_amd import scenes
+    from tests import oracle_lib as ol
+    lib = ol.load()
+    ctxs = [ol.OracleContext(lib, rng_literal=True) for _ in range(threads)]
+    rng = np.random.default_rng(1)
+    cams = []
+    for _ in range(threads):
+        j = rng.normal(size=3)
+        cams.append(scenes.default_camera(w, h, jitter=0.00015 * j / np.linalg.norm(j)))
+    for c in ctxs:
+        c.set_scene(scene)
+
+    def run(fn):
+        ts = [threading.Thread(target=fn, args=(i,)) for i in range(threads)]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        return time.perf_counter() - t0
+
+    t_eye = run(lambda i: ctxs[i].eye_pass(cams[i], SEED, i))
+    t_ph = run(lambda i: ctxs[i].photon_pass(rounds, 100, SEED, i, mode=ol.GATHER_KDTREE))
+    photons = threads * rounds * 100
+    for c in ctxs:
+        c.close()
+    return {
+        "value": photons / t_ph / 1e6, "unit": "Mphotons/s", "cores": threads, "kind": "port",
+        "sample": f"{threads} replicas x {rounds * 100} photons ({rounds} rounds x 100) on the {w}x{h} teapot scene, "
+                  f"photon pass {t_ph:.1f} s (eye pass {t_eye:.1f} s not counted), oracle literal mode: fp64, kd-tree "
+                  f"radius search, per-round update() sweep",
+        "eye_pass_s": t_eye, "photon_pass_s": t_ph,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2_teapot_800x600")
+    ap.add_argument("--rounds", type=int, default=0, help="rounds per GPU per step (default: the config's)")
+    ap.add_argument("--cpu-rounds", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raytrace3_amd import SppmContext, scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    factory, (w, h), cfg_rounds, per_round = scenes.CONFIGS[args.config]
+    rounds = args.rounds or cfg_rounds
+    scene = factory()
+    cam = scenes.default_camera(w, h)
+    ctx = SppmContext(local_rank)
+    ctx.set_scene(scene)
+    n_lights = len(scene.light_list)
+    per_rank = rounds * per_round * n_lights
+    total_rounds = rounds * world
+    pic = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+
+    def step(i):
+        ctx.eye_pass(cam, SEED, replica=i)
+        ctx.photon_pass(total_rounds, per_round, SEED, replica=i, photon_begin=rank * per_rank, photon_count=per_rank)
+        ctx.resolve_device(pic.data_ptr())
+        if world > 1:
+            dist.all_reduce(pic)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    acc = {k: 0.0 for k in ("eye_trace_ms", "grid_build_ms", "photon_trace_ms", "deposit_sort_ms", "gather_ms", "resolve_ms")}
+    gather_launches = 0
+    bytes_model = 0.0
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+        tm = ctx.timings()          # HIP-event durations measured on the library's stream
+        for k in acc:
+            acc[k] += tm[k]
+        gather_launches += tm["gather_launches"]
+        c = ctx.counters()
+        bytes_model += 40.0 * c["candidates"] + 32.0 * c["accepted"] + 64.0 * c["segments"]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    counters = ctx.counters()
+
+    if rank == 0:
+        photons_total = per_rank * world * args.steps
+        gather_s = acc["gather_ms"] / 1e3
+        achieved = bytes_model / gather_s / 1e9 if gather_s > 0 else 0.0
+        pass_s = (acc["photon_trace_ms"] + acc["deposit_sort_ms"] + acc["gather_ms"]) / 1e3
+        out = {
+            "metric": "Mphotons/s", "value": photons_total / elapsed / 1e6, "unit": "Mphotons/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 rays/gather + f32 Newton/flux", "data": "synthetic",
+            "config": {"workload": f"{args.config}: teapot.bpt Cornell scene {w}x{h}, {per_rank} photons/iter/GPU "
+                                   f"({rounds} rounds x {per_round}), one replica per step, photon-sharded over {world} GPU(s)",
+                       "hitpoints": counters["hitpoints"]},
+            "photon_pass_mphotons_per_s": per_rank * args.steps / pass_s / 1e6 if pass_s > 0 else None,
+            "kernel_ms_per_step": {k: v / args.steps for k, v in acc.items()},
+            "counters_last_step": counters,
+            "roofline": {"kernel": "k_gather", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_model": "40*candidates + 32*accepted + 64*segments per launch",
+                         "avg_launch_ms": acc["gather_ms"] / max(1, gather_launches)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(scene, w, h, args.cpu_rounds, 4)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
