@@ -82,6 +82,7 @@ def main():
     import torch
     import torch.distributed as dist
     from raytrace3_amd import SppmContext, scenes
+    from raytrace3_amd import distributed as D
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -106,11 +107,7 @@ def main():
     pic = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
 
     def step(i):
-        ctx.eye_pass(cam, SEED, replica=i)
-        ctx.photon_pass(total_rounds, per_round, SEED, replica=i, photon_begin=rank * per_rank, photon_count=per_rank)
-        ctx.resolve_device(pic.data_ptr())
-        if world > 1:
-            dist.all_reduce(pic)
+        D.sharded_iteration(ctx, cam, SEED, i, total_rounds, per_round, n_lights, rank, world, pic_tensor=pic)
 
     def fence():
         if world > 1:

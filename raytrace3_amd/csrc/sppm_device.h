@@ -336,6 +336,7 @@ __device__ __forceinline__ void bezier_coop(const SceneView& S, const DevObject&
                                             float& out_t, float& out_u, float& out_v, int& out_patch, uint32_t& newton_calls) {
     const int lane = lane_id();
     out_patch = -1; out_t = (float)SPPM_MAX_NUM; out_u = 0; out_v = 0;
+    const int n_patches = __builtin_amdgcn_readfirstlane(ob.n_patches), first_patch = __builtin_amdgcn_readfirstlane(ob.first_patch);
     uint64_t m = __ballot(need);
     while (m) {
         int src = __ffsll((unsigned long long)m) - 1;
@@ -346,12 +347,12 @@ __device__ __forceinline__ void bezier_coop(const SceneView& S, const DevObject&
         f3 fo = {(float)so.x, (float)so.y, (float)so.z}, fd = {(float)sd.x, (float)sd.y, (float)sd.z};
         float pt = (float)SPPM_MAX_NUM, pu = (float)SPPM_MAX_NUM, pv = (float)SPPM_MAX_NUM;  // para = MAX_VEC3
         int pidx = -1;
-        for (int base = 0; base < ob.n_patches; base += 64) {
-            int p = ob.first_patch + base + lane;
-            bool ph = (base + lane < ob.n_patches) && aabb_hit(S.patch_box + 6 * p, so, sd);   // Bezier3::intersect, Bezier.h:176-186
+        for (int base = 0; base < n_patches; base += 64) {
+            int p = first_patch + base + lane;
+            bool ph = (base + lane < n_patches) && aabb_hit(S.patch_box + 6 * p, so, sd);      // Bezier3::intersect, Bezier.h:176-186
             uint64_t pm = __ballot(ph);
             while (pm) {
-                int pi = ob.first_patch + base + (__ffsll((unsigned long long)pm) - 1);
+                int pi = first_patch + base + (__ffsll((unsigned long long)pm) - 1);
                 pm &= pm - 1;
                 float t, u, v;
                 newton_coop(S.patch_cp, pi, fo, fd, ssub, t, u, v);
@@ -374,14 +375,15 @@ __device__ __forceinline__ Hit near_collide(const SceneView& S, bool active, d3 
     float best_u = 0, best_v = 0, best_t = 0;
     for (int a = 0; a < S.n_objs; a++) {
         const DevObject& ob = S.objs[a];
-        if (ob.type == OBJ_PLANE) {                                                       // Obj.h:65-85
+        const int type = __builtin_amdgcn_readfirstlane(ob.type);   // wave-uniform: keep the branch scalar
+        if (type == OBJ_PLANE) {                                                          // Obj.h:65-85
             d3 n = ld3(ob.n);
             double project = dot(d, n);
             if (active && !is_zero(project)) {
                 double dist = dot(ld3(ob.p0) - o, n) / project;
                 if (dist > SPPM_EPS && dist < mindist) { mindist = dist; best = a; best_inside = 0; }
             }
-        } else if (ob.type == OBJ_SPHERE) {                                               // Obj.h:111-139
+        } else if (type == OBJ_SPHERE) {                                                  // Obj.h:111-139
             d3 L = ld3(ob.p0) - o;
             double project = dot(L, d);
             double det2 = ob.radius * ob.radius - (dot(L, L) - project * project);

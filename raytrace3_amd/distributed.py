@@ -1,0 +1,49 @@
+"""Multi-GPU host logic: one process per GPU, photons of one pass sharded by index, one
+all-reduce (sum) of the per-pixel flux image per SPPM iteration.
+
+The reference's only parallelism is four independent replicas whose images are added
+(raytracer/Raytracer.h:442-458).  Because HitPoint::update() never runs (Raytracer.h:74) and
+the resolve is linear in tao (Raytracer.h:288-293), a pass can equally be split by photon
+index: every rank runs the cheap eye pass, traces its own photon range, resolves its partial
+flux image with the normaliser of the WHOLE pass, and the images add up.
+"""
+import os
+
+
+def photon_shard(total_photons, rank, world):
+    """[begin, count) of rank's contiguous share of a pass of total_photons photons."""
+    base, rem = divmod(int(total_photons), int(world))
+    begin = rank * base + min(rank, rem)
+    count = base + (1 if rank < rem else 0)
+    return begin, count
+
+
+def rank_info():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def all_reduce_image(pic):
+    """Sum the flux image over ranks in place (RCCL on GPU tensors, gloo on CPU tensors)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(pic, op=dist.ReduceOp.SUM)
+    return pic
+
+
+def sharded_iteration(ctx, cam, seed, replica, total_rounds, per_round, n_lights, rank, world, pic_tensor=None):
+    """One SPPM iteration of one replica on this rank's shard.  ctx is any object with the
+    SppmContext methods; pic_tensor (device float32 [h,w,3]) receives the partial image and is
+    all-reduced in place; without it the host image is returned un-reduced."""
+    total = total_rounds * per_round * n_lights
+    begin, count = photon_shard(total, rank, world)
+    ctx.eye_pass(cam, seed, replica)
+    if count > 0:
+        ctx.photon_pass(total_rounds, per_round, seed, replica, photon_begin=begin, photon_count=count)
+    else:
+        # photon_count == 0 means "all" at the C-ABI, so an empty shard traces a zero-length range
+        ctx.photon_pass(total_rounds, per_round, seed, replica, photon_begin=total, photon_count=1)
+    if pic_tensor is not None:
+        ctx.resolve_device(pic_tensor.data_ptr())
+        return all_reduce_image(pic_tensor)
+    return ctx.resolve()
