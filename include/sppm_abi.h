@@ -215,6 +215,16 @@ int sppm_debug_near_collide(sppm_ctx* ctx, uint64_t n, const double* org, const 
 int sppm_debug_newton(sppm_ctx* ctx, uint64_t n, const double* org, const double* dir,
                       const int32_t* patch, uint64_t seed, uint32_t replica, double* out_tuv);
 
+/* Parity hook: the deposit records (diffuse photon hits = the radius-search queries of
+ * raytracer/Raytracer.h:136-146) of the photons [photon_begin, +photon_count) of a pass, in
+ * device order.  out: cap x 11 doubles = photon index, bounce, pos[3], n[3], flux[3] (flux is
+ * the photon's flux before the hit's colour is applied).  Needs a prior sppm_eye_pass; does not
+ * touch the HitPoints or the counters. */
+int sppm_debug_photon_deposits(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round,
+                               uint64_t photon_begin, uint64_t photon_count,
+                               uint64_t seed, uint32_t replica,
+                               double* out, uint64_t cap, uint64_t* n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,6 +100,8 @@ ABI_SYMBOLS = {
     "sppm_get_timings": (C.c_int, [C.c_void_p, C.POINTER(Timings)]),
     "sppm_debug_near_collide": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.c_uint64, C.c_uint32, C.c_void_p]),
+    "sppm_debug_photon_deposits": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
+                                             C.POINTER(C.c_double), C.c_uint64, C.POINTER(C.c_uint64)]),
     "sppm_debug_newton": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_int32), C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
 }
@@ -219,3 +221,10 @@ class SppmContext:
                                                patch.ctypes.data_as(C.POINTER(C.c_int32)), seed, replica, _dptr(out)),
                     "sppm_debug_newton")
         return out
+
+    def deposits(self, rounds, per_round, seed, replica=0, photon_begin=0, photon_count=1, cap=1 << 20):
+        out = np.zeros((cap, 11), dtype=np.float64)
+        n = C.c_uint64(0)
+        self._check(self.lib.sppm_debug_photon_deposits(self._ctx, rounds, per_round, photon_begin, photon_count, seed, replica,
+                                                        _dptr(out), cap, C.byref(n)), "sppm_debug_photon_deposits")
+        return out[:n.value]

@@ -28,7 +28,8 @@ using namespace sppm;
 
 // ------------------------------------------------------------------ device records
 struct __attribute__((aligned(32))) PosKey { double x, y, z; uint64_t key; };
-struct __attribute__((aligned(32))) DepB { float nx, ny, nz, fr, fg, fb; uint32_t bucket, pad; };
+// bucket: grid bucket in bits 0..23, path vertex (bounce) in bits 24..31; photon: global photon index
+struct __attribute__((aligned(32))) DepB { float nx, ny, nz, fr, fg, fb; uint32_t bucket, photon; };
 struct RawHit { double pos[3]; float n[3]; float v[3]; float wgt[3]; int pix, node, obj; };
 struct HpMeta { float v[3]; int node, obj, N; };
 struct EyeTask { double o[3]; double d[3]; float wgt[3]; int pix, node, dep; };
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(256) k_photon_trace(SceneParams sp, PhotonPara
                 da.key = cell_key(hit.pos, pp.grid.inv_cs);
                 db.nx = (float)hit.n.x; db.ny = (float)hit.n.y; db.nz = (float)hit.n.z;
                 db.fr = flux[0]; db.fg = flux[1]; db.fb = flux[2];
-                db.bucket = key_bucket(da.key, pp.grid.mask); db.pad = 0;
+                db.bucket = key_bucket(da.key, pp.grid.mask) | (vertex << 24); db.photon = pid;
             }
             // Obj::Roulette, Obj.h:30-45
             double r = rng_u01(rng_sub(pp.rng, pid, vertex, P_ROULETTE), 0) * ob.allr;
@@ -343,7 +344,7 @@ __global__ void __launch_bounds__(256) k_photon_trace(SceneParams sp, PhotonPara
             ndep++;
             if (slot < pp.dep_cap) {
                 pp.depA[slot] = da; pp.depB[slot] = db;
-                atomicAdd(&pp.dcount[db.bucket], 1u);
+                atomicAdd(&pp.dcount[db.bucket & 0xffffffu], 1u);
             } else atomicOr(&pp.counters->overflow, 4u);
         }
     }
@@ -359,7 +360,8 @@ __global__ void k_dep_scatter(const PosKey* depA, const DepB* depB, const unsign
     for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * blockDim.x) {
         DepB b = depB[i];
-        uint32_t s = start[b.bucket] + atomicAdd(&cursor[b.bucket], 1u);
+        const uint32_t bk = b.bucket & 0xffffffu;
+        uint32_t s = start[bk] + atomicAdd(&cursor[bk], 1u);
         sA[s] = depA[i];
         sB[s] = b;
     }
@@ -1003,6 +1005,55 @@ int sppm_debug_near_collide(sppm_ctx* ctx, uint64_t n, const double* org, const 
     } while (0);
     o.release(); d.release(); c.release();
     return rc;
+}
+
+int sppm_debug_photon_deposits(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_t photon_begin, uint64_t photon_count,
+                               uint64_t seed, uint32_t replica, double* out, uint64_t cap, uint64_t* n) {
+    if (!ctx || !n || (!out && cap)) return SPPM_E_INVALID;
+    if (!ctx->have_eye) return fail(ctx, SPPM_E_INVALID, "sppm_eye_pass must come first");
+    if (rounds == 0 || per_round == 0 || photon_count == 0) return fail(ctx, SPPM_E_INVALID, "empty photon range");
+    const uint64_t total = rounds * (uint64_t)ctx->n_lights * per_round;
+    if (photon_begin >= total) return fail(ctx, SPPM_E_INVALID, "photon_begin beyond the pass");
+    const uint64_t count = std::min(photon_count, total - photon_begin);
+    if (count > (1u << 22)) return fail(ctx, SPPM_E_INVALID, "at most 2^22 photons per debug call");
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t M = ctx->grid.mask + 1;
+    const uint64_t dep_cap = count * (SPPM_MAX_DEP + 1);
+    HIPCHK(ctx->depA.reserve(dep_cap)); HIPCHK(ctx->depB.reserve(dep_cap));
+    HIPCHK(ctx->sdepA.reserve(dep_cap)); HIPCHK(ctx->sdepB.reserve(dep_cap));
+    DevBuf<DevCounters> scratch_counters;   // keep the pass counters untouched
+    HIPCHK(scratch_counters.reserve(1));
+    HIPCHK(hipMemsetAsync(scratch_counters.p, 0, sizeof(DevCounters), ctx->stream));
+    PhotonParams pp;
+    pp.lights = ctx->lights.p; pp.n_lights = ctx->n_lights; pp.per_round = per_round;
+    pp.first = photon_begin; pp.count = count;
+    pp.next = ctx->scalars.p + 2; pp.n_dep = ctx->scalars.p + 3;
+    pp.depA = ctx->depA.p; pp.depB = ctx->depB.p; pp.dep_cap = dep_cap;
+    pp.dcount = ctx->dcount.p; pp.grid = ctx->grid; pp.counters = scratch_counters.p;
+    pp.rng = host_rng_base(seed, replica * 4u + D_PHOTON);
+    HIPCHK(hipMemsetAsync(ctx->scalars.p + 2, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    if (int rc = launch_fill(ctx, ctx->dcount.p, M + 1, 0)) { scratch_counters.release(); return rc; }
+    hipLaunchKernelGGL(k_photon_trace, dim3(ctx->num_cu * 4), dim3(256), (size_t)ctx->blob_bytes, ctx->stream, ctx->scene_params(), pp);
+    unsigned long long nd = 0;
+    hipError_t e = hipMemcpyAsync(&nd, ctx->scalars.p + 3, sizeof(nd), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    scratch_counters.release();
+    if (e != hipSuccess) return fail(ctx, SPPM_E_DEVICE, hipGetErrorString(e));
+    *n = nd;
+    const uint64_t m = std::min<uint64_t>(nd, cap);
+    if (m) {
+        std::vector<PosKey> a(m); std::vector<DepB> b(m);
+        HIPCHK(hipMemcpy(a.data(), ctx->depA.p, m * sizeof(PosKey), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(b.data(), ctx->depB.p, m * sizeof(DepB), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < m; i++) {
+            double* o = out + 11 * i;
+            o[0] = (double)b[i].photon; o[1] = (double)(b[i].bucket >> 24);
+            o[2] = a[i].x; o[3] = a[i].y; o[4] = a[i].z;
+            o[5] = b[i].nx; o[6] = b[i].ny; o[7] = b[i].nz;
+            o[8] = b[i].fr; o[9] = b[i].fg; o[10] = b[i].fb;
+        }
+    }
+    return nd <= cap ? SPPM_OK : SPPM_E_CAPACITY;
 }
 
 int sppm_debug_newton(sppm_ctx* ctx, uint64_t n, const double* org, const double* dir, const int32_t* patch, uint64_t seed,
