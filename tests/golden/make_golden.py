@@ -36,6 +36,24 @@ def hitpoints_and_image():
                         counter_names=np.array(list(o.counters().keys())))
 
 
+def bernstein(t):
+    return np.array([(1 - t) ** 3, 3 * t * (1 - t) ** 2, 3 * t * t * (1 - t), t ** 3])
+
+
+def newton_targets(P, patch, rng):
+    """Aim points: interior surface points S(u,v), (u,v) in [0.1,0.9]^2, three quarters of them
+    exactly on the surface and a quarter pushed 0.3 off it (near misses)."""
+    tgt = []
+    for k, p in enumerate(patch):
+        u, v = rng.random(2) * 0.8 + 0.1
+        cp = P[p].reshape(4, 4, 3)          # [i (v index)][k (u index)]
+        s = np.einsum("i,k,ikc->c", bernstein(v), bernstein(u), cp)
+        if k % 4 == 3:
+            s = s + rng.normal(size=3) * 0.3
+        tgt.append(s)
+    return np.array(tgt)
+
+
 def newton_cases():
     scene = scenes.scene_teapot(1, textured=False)
     P = scene.patches
@@ -43,8 +61,7 @@ def newton_cases():
     n = 256
     patch = rng.integers(0, 32, size=n).astype(np.int32)
     org = np.tile([50., 35., 230.], (n, 1)) + rng.normal(size=(n, 3)) * 20
-    uv = rng.random((n, 2))
-    tgt = np.array([P[p].reshape(4, 4, 3)[int(a * 3.999), int(b * 3.999)] for p, (a, b) in zip(patch, uv)])
+    tgt = newton_targets(P, patch, rng)
     d = tgt - org
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     o64 = ol.OracleContext()
