@@ -214,25 +214,60 @@ __global__ void k_hp_count(const RawHit* hits, uint32_t n, GridParams g, uint32_
     atomicAdd(&count[b], 1u);
 }
 
-// start[i] = sum_{j<i} cnt[j] for i in [0, n]; one workgroup.
-__global__ void __launch_bounds__(1024) k_scan(const uint32_t* cnt, uint32_t* start, uint32_t n) {
-    __shared__ uint32_t part[1024];
-    const uint32_t t = threadIdx.x;
-    const uint32_t chunk = (n + 1023u) / 1024u;
-    const uint32_t b = t * chunk, e = min(n, b + chunk);
-    uint32_t s = 0;
-    for (uint32_t i = b; i < e; i++) s += cnt[i];
-    part[t] = s;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint32_t v = (t >= off) ? part[t - off] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+// Exclusive prefix sum start[i] = sum_{j<i} cnt[j], i in [0, n], in three launches:
+// per-tile sums, a one-workgroup scan of the tile sums, per-tile scan + offset.
+#define SCAN_THREADS 256
+#define SCAN_PER_THREAD 8
+#define SCAN_TILE (SCAN_THREADS * SCAN_PER_THREAD)
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* total) {
+    __shared__ uint32_t wsum[4];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64);
+        if (lane >= off) inc += o;
     }
-    uint32_t run = part[t] - s;
-    for (uint32_t i = b; i < e; i++) { start[i] = run; run += cnt[i]; }
-    if (t == 1023) start[n] = part[1023];
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { uint32_t s = wsum[k]; if (k < w) base += s; tot += s; }
+    __syncthreads();
+    if (total) *total = tot;
+    return base + inc - v;
+}
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_reduce(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* __restrict__ partial) {
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; k++) if (base + k < n) s += cnt[base + k];
+    uint32_t tot;
+    block_exclusive_scan_256(s, &tot);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+// nb <= SCAN_TILE tile sums, exclusive-scanned in place; partial[nb] = grand total.
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_partials(uint32_t* partial, uint32_t nb) {
+    const uint32_t base = threadIdx.x * SCAN_PER_THREAD;
+    uint32_t v[SCAN_PER_THREAD], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; k++) { v[k] = (base + k < nb) ? partial[base + k] : 0; s += v[k]; }
+    uint32_t tot;
+    uint32_t run = block_exclusive_scan_256(s, &tot);
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; k++) { if (base + k < nb) partial[base + k] = run; run += v[k]; }
+    if (threadIdx.x == 0) partial[nb] = tot;
+}
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_final(const uint32_t* __restrict__ cnt, uint32_t n, const uint32_t* __restrict__ partial,
+                                                             uint32_t nb, uint32_t* __restrict__ start) {
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+    uint32_t v[SCAN_PER_THREAD], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; k++) { v[k] = (base + k < n) ? cnt[base + k] : 0; s += v[k]; }
+    uint32_t run = block_exclusive_scan_256(s, nullptr) + partial[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; k++) { if (base + k < n) start[base + k] = run; run += v[k]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) start[n] = partial[nb];
 }
 
 __global__ void k_hp_scatter(const RawHit* hits, uint32_t n, GridParams g, const uint32_t* bucket_of, const uint32_t* start,
@@ -560,7 +595,7 @@ struct sppm_ctx {
     GridParams grid{};
     // photon pass
     DevBuf<PosKey> depA, sdepA; DevBuf<DepB> depB, sdepB;
-    DevBuf<uint32_t> dcount, dstart;
+    DevBuf<uint32_t> dcount, dstart, scan_partial;
     DevBuf<unsigned long long> scalars;   // [0] n_hits, [1] n_tasks_out, [2] next photon, [3] n_dep
     DevBuf<DevCounters> counters;
     DevBuf<float> pic;
@@ -650,7 +685,7 @@ void sppm_destroy(sppm_ctx* ctx) {
     ctx->bucket_of.release(); ctx->hcount.release(); ctx->hstart.release(); ctx->cursor.release();
     ctx->hp_pos.release(); ctx->hp_nr.release(); ctx->hp_wgt.release(); ctx->hp_tao.release(); ctx->hp_meta.release();
     ctx->depA.release(); ctx->sdepA.release(); ctx->depB.release(); ctx->sdepB.release();
-    ctx->dcount.release(); ctx->dstart.release(); ctx->scalars.release(); ctx->counters.release(); ctx->pic.release();
+    ctx->dcount.release(); ctx->dstart.release(); ctx->scan_partial.release(); ctx->scalars.release(); ctx->counters.release(); ctx->pic.release();
     if (ctx->ev[0]) (void)hipEventDestroy(ctx->ev[0]);
     if (ctx->ev[1]) (void)hipEventDestroy(ctx->ev[1]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -762,6 +797,18 @@ static int launch_fill(sppm_ctx* ctx, uint32_t* p, size_t n, uint32_t v) {
     return SPPM_OK;
 }
 
+// start[0..n] = exclusive prefix sums of cnt[0..n-1]; n <= SCAN_TILE^2.
+static int launch_scan(sppm_ctx* ctx, const uint32_t* cnt, uint32_t* start, uint32_t n) {
+    const uint32_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (nb > SCAN_TILE) return fail(ctx, SPPM_E_INVALID, "scan too large");
+    HIPCHK(ctx->scan_partial.reserve(SCAN_TILE + 1));
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, ctx->stream, cnt, n, ctx->scan_partial.p);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, ctx->scan_partial.p, nb);
+    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, ctx->stream, cnt, n, ctx->scan_partial.p, nb, start);
+    HIPCHK(hipGetLastError());
+    return SPPM_OK;
+}
+
 int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t replica) {
     if (!ctx || !cam) return SPPM_E_INVALID;
     if (!ctx->have_scene) return fail(ctx, SPPM_E_INVALID, "sppm_set_scene must come first");
@@ -834,7 +881,7 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
     if (n > 0) {
         const int blocks = (int)((n + 255) / 256);
         hipLaunchKernelGGL(k_hp_count, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)n, ctx->grid, ctx->bucket_of.p, ctx->hcount.p);
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->hcount.p, ctx->hstart.p, M);
+        if (int rc = launch_scan(ctx, ctx->hcount.p, ctx->hstart.p, M)) return rc;
         hipLaunchKernelGGL(k_hp_scatter, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)n, ctx->grid, ctx->bucket_of.p,
                            ctx->hstart.p, ctx->cursor.p, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->hp_tao.p, ctx->hp_meta.p);
         HIPCHK(hipGetLastError());
@@ -882,7 +929,7 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
         HIPCHK(hipGetLastError());
         ctx->tm.photon_trace_ms += toc(ctx);
         tic(ctx);
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->dcount.p, ctx->dstart.p, M);
+        if (int rc = launch_scan(ctx, ctx->dcount.p, ctx->dstart.p, M)) return rc;
         hipLaunchKernelGGL(k_dep_scatter, dim3(ctx->num_cu * 8), dim3(256), 0, ctx->stream, ctx->depA.p, ctx->depB.p, ctx->scalars.p + 3,
                            dep_cap, ctx->dstart.p, ctx->cursor.p, ctx->sdepA.p, ctx->sdepB.p);
         HIPCHK(hipGetLastError());
