@@ -64,6 +64,7 @@ struct SceneView {
     const DevObject* objs;      // LDS
     const double* patch_box;    // LDS, n_patches x 6 (pmin, pmax)
     const float* patch_cp;      // LDS, n_patches x 48
+    const int* patch_obj;       // LDS, n_patches: owning object of each patch
     int n_objs;
     int n_patches;
     const TexDesc* tex;         // global
@@ -320,14 +321,6 @@ __device__ __forceinline__ void newton_coop(const float* __restrict__ cp_lds, in
 }
 
 // ------------------------------------------------------------------ Scene::NearCollide (Scene.h:165-182)
-struct Hit {
-    d3 pos, n;
-    float color[3];
-    double dist;
-    int obj;      // -1 = none
-    int inside;
-};
-
 // Bezier3Obj::GetIntersect (Bezier.h:240-282) for the lanes of one wave.  `need` marks
 // lanes whose ray passed the object AABB.  For each such ray in turn the wave tests the
 // patch AABBs one per lane, then solves every hit patch cooperatively.  On return the
@@ -367,53 +360,117 @@ __device__ __forceinline__ void bezier_coop(const SceneView& S, const DevObject&
     }
 }
 
-// All lanes of the wave must call this together (it contains wave-cooperative
-// sections); lanes with active = false take part but get obj = -1.
-__device__ __forceinline__ Hit near_collide(const SceneView& S, bool active, d3 o, d3 d, uint32_t newton_sub, uint32_t& newton_calls) {
-    double mindist = SPPM_MAX_NUM;
-    int best = -1, best_inside = 0, best_patch = -1;
-    float best_u = 0, best_v = 0, best_t = 0;
+// Running nearest-hit record of Scene::NearCollide (Scene.h:165-182).  The reference walks
+// objvec in order and replaces on strictly smaller dist, i.e. the winner is the minimum of
+// (dist, object index); consider() applies that rule so analytic and Bezier candidates can be
+// merged in any order.
+struct Near {
+    double dist;
+    int obj, inside, patch;
+    float t, u, v;
+};
+__device__ __forceinline__ void near_init(Near& n) {
+    n.dist = SPPM_MAX_NUM; n.obj = -1; n.inside = 0; n.patch = -1; n.t = 0; n.u = 0; n.v = 0;
+}
+__device__ __forceinline__ void near_consider(Near& n, double dist, int obj, int inside, int patch, float t, float u, float v) {
+    if (dist < n.dist || (dist == n.dist && obj < n.obj)) {
+        n.dist = dist; n.obj = obj; n.inside = inside; n.patch = patch; n.t = t; n.u = u; n.v = v;
+    }
+}
+
+// Planes and spheres (Obj.h:65-85, :111-139), per lane, fp64.
+__device__ __forceinline__ void analytic_nearest(const SceneView& S, bool active, d3 o, d3 d, Near& nr) {
     for (int a = 0; a < S.n_objs; a++) {
         const DevObject& ob = S.objs[a];
         const int type = __builtin_amdgcn_readfirstlane(ob.type);   // wave-uniform: keep the branch scalar
-        if (type == OBJ_PLANE) {                                                          // Obj.h:65-85
+        if (type == OBJ_PLANE) {
             d3 n = ld3(ob.n);
             double project = dot(d, n);
             if (active && !is_zero(project)) {
                 double dist = dot(ld3(ob.p0) - o, n) / project;
-                if (dist > SPPM_EPS && dist < mindist) { mindist = dist; best = a; best_inside = 0; }
+                if (dist > SPPM_EPS) near_consider(nr, dist, a, 0, -1, 0, 0, 0);
             }
-        } else if (type == OBJ_SPHERE) {                                                  // Obj.h:111-139
+        } else if (type == OBJ_SPHERE) {
             d3 L = ld3(ob.p0) - o;
             double project = dot(L, d);
             double det2 = ob.radius * ob.radius - (dot(L, L) - project * project);
             if (active && !(det2 < SPPM_EPS)) {
                 double det = sqrt(det2);
                 double dist1 = project - det, dist2 = project + det;
-                if (!(dist2 < SPPM_EPS)) {
-                    double dist = (dist1 > SPPM_EPS) ? dist1 : dist2;
-                    if (dist < mindist) { mindist = dist; best = a; best_inside = (dist1 < SPPM_EPS) ? 1 : 0; }
-                }
-            }
-        } else {                                                                          // Bezier.h:240-282
-            bool need = active && aabb_hit(ob.bmin, o, d);
-            float t, u, v;
-            int patch;
-            bezier_coop(S, ob, need, o, d, newton_sub, t, u, v, patch, newton_calls);
-            if (need && patch >= 0 && (double)t < mindist) {
-                mindist = (double)t; best = a; best_inside = 0;
-                best_patch = patch; best_t = t; best_u = u; best_v = v;
+                if (!(dist2 < SPPM_EPS)) near_consider(nr, (dist1 > SPPM_EPS) ? dist1 : dist2, a, (dist1 < SPPM_EPS) ? 1 : 0, -1, 0, 0, 0);
             }
         }
     }
-    // Collision of the winner only (GetColor is a pure function, so evaluating it for
-    // the nearest object alone gives what the reference's per-object evaluation gives).
+}
+
+// Bezier objects, solved inside the calling wave (Bezier.h:240-282).
+__device__ __forceinline__ void bezier_nearest_coop(const SceneView& S, bool active, d3 o, d3 d, uint32_t newton_sub, Near& nr, uint32_t& newton_calls) {
+    for (int a = 0; a < S.n_objs; a++) {
+        const DevObject& ob = S.objs[a];
+        if (__builtin_amdgcn_readfirstlane(ob.type) != OBJ_BEZIER) continue;
+        bool need = active && aabb_hit(ob.bmin, o, d);
+        float t, u, v;
+        int patch;
+        bezier_coop(S, ob, need, o, d, newton_sub, t, u, v, patch, newton_calls);
+        if (need && patch >= 0) near_consider(nr, (double)t, a, 0, patch, t, u, v);
+    }
+}
+
+// Bezier objects, deferred: only the AABB culls (object box per lane, patch boxes one per lane
+// for one ray at a time, Bezier.h:176-186, :244).  words[] receives a bit per patch (global
+// patch index, up to 256) whose box the lane's ray enters; the Newton solves run in k_newton.
+#define SPPM_MASK_WORDS 4
+__device__ __forceinline__ void bezier_patch_masks(const SceneView& S, bool active, d3 o, d3 d, uint64_t words[SPPM_MASK_WORDS]) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int w = 0; w < SPPM_MASK_WORDS; w++) words[w] = 0;
+    for (int a = 0; a < S.n_objs; a++) {
+        const DevObject& ob = S.objs[a];
+        if (__builtin_amdgcn_readfirstlane(ob.type) != OBJ_BEZIER) continue;
+        const int n_patches = __builtin_amdgcn_readfirstlane(ob.n_patches), first_patch = __builtin_amdgcn_readfirstlane(ob.first_patch);
+        bool need = active && aabb_hit(ob.bmin, o, d);
+        uint64_t m = __ballot(need);
+        while (m) {
+            int src = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            d3 so = mk(bcast_d(o.x, src), bcast_d(o.y, src), bcast_d(o.z, src));
+            d3 sd = mk(bcast_d(d.x, src), bcast_d(d.y, src), bcast_d(d.z, src));
+            for (int base = 0; base < n_patches; base += 64) {
+                int p = first_patch + base + lane;
+                bool ph = (base + lane < n_patches) && aabb_hit(S.patch_box + 6 * p, so, sd);
+                uint64_t pm = __ballot(ph);
+                if (pm == 0) continue;
+                const int g = first_patch + base, wi = g >> 6, sh = g & 63;
+                const uint64_t lo = pm << sh, hi = sh ? (pm >> (64 - sh)) : 0ull;
+                if (lane == src) {
+#pragma unroll
+                    for (int w = 0; w < SPPM_MASK_WORDS; w++) {
+                        if (w == wi) words[w] |= lo;
+                        if (w == wi + 1) words[w] |= hi;
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct Hit {
+    d3 pos, n;
+    float color[3];
+    double dist;
+    int obj;      // -1 = none
+    int inside;
+};
+
+// Collision of the winner only (GetColor is a pure function, so evaluating it for the nearest
+// object alone gives what the reference's per-object evaluation gives).
+__device__ __forceinline__ Hit finish_hit(const SceneView& S, d3 o, d3 d, const Near& nr) {
     Hit h;
-    h.obj = best; h.dist = mindist; h.inside = best_inside;
+    h.obj = nr.obj; h.dist = nr.dist; h.inside = nr.inside;
     h.pos = mk(0, 0, 0); h.n = mk(0, 0, 0); h.color[0] = h.color[1] = h.color[2] = 0;
-    if (best >= 0) {
-        const DevObject& ob = S.objs[best];
-        h.pos = o + d * mindist;
+    if (nr.obj >= 0) {
+        const DevObject& ob = S.objs[nr.obj];
+        h.pos = o + d * nr.dist;
         h.color[0] = ob.color[0]; h.color[1] = ob.color[1]; h.color[2] = ob.color[2];
         if (ob.type == OBJ_PLANE) {
             h.n = ld3(ob.n);
@@ -443,20 +500,26 @@ __device__ __forceinline__ Hit near_collide(const SceneView& S, bool active, d3 
             }
         } else {
             // normal = Su x Sv at the winning (u, v), turned against the ray (Bezier.h:267-273)
-            float P[48];
-            const float* src = S.patch_cp + best_patch * 48;
-#pragma unroll
-            for (int k = 0; k < 48; k++) P[k] = src[k];
             f3 Sp, Su, Sv;
-            patch_eval(P, best_u, best_v, Sp, Su, Sv);
+            patch_eval(S.patch_cp + nr.patch * 48, nr.u, nr.v, Sp, Su, Sv);   // control points read straight from LDS
             d3 N = cross(mk(Su.x, Su.y, Su.z), mk(Sv.x, Sv.y, Sv.z));
             if (dot(N, d) > 0) N = neg(N);
             h.n = get_unit(N);
             // GetColor(u, t): the second texture coordinate is the ray parameter (Bezier.h:278)
-            if (ob.texture >= 0) color_uv(S.tex[ob.texture], S.texels, (double)best_u, (double)best_t, h.color);
+            if (ob.texture >= 0) color_uv(S.tex[ob.texture], S.texels, (double)nr.u, (double)nr.t, h.color);
         }
     }
     return h;
+}
+
+// Scene::NearCollide with the Bezier solves done inside the wave.  All lanes of the wave must
+// call this together; lanes with active = false take part but get obj = -1.
+__device__ __forceinline__ Hit near_collide(const SceneView& S, bool active, d3 o, d3 d, uint32_t newton_sub, uint32_t& newton_calls) {
+    Near nr;
+    near_init(nr);
+    analytic_nearest(S, active, o, d, nr);
+    bezier_nearest_coop(S, active, o, d, newton_sub, nr, newton_calls);
+    return finish_hit(S, o, d, nr);
 }
 
 }  // namespace sppm

@@ -32,11 +32,22 @@ struct __attribute__((aligned(32))) PosKey { double x, y, z; uint64_t key; };
 struct __attribute__((aligned(32))) DepB { float nx, ny, nz, fr, fg, fb; uint32_t bucket, photon; };
 struct RawHit { double pos[3]; float n[3]; float v[3]; float wgt[3]; int pix, node, obj; };
 struct HpMeta { float v[3]; int node, obj, N; };
-struct EyeTask { double o[3]; double d[3]; float wgt[3]; int pix, node, dep; };
+// A parked ray: either one whose Bezier patch solves were deferred to k_newton (task_count > 0;
+// adist / aobj / ainside hold the nearest plane-or-sphere hit) or a fresh ray still to be traced
+// (task_count == 0: the refraction branch of an eye path that also reflects).
+struct __attribute__((aligned(16))) ParkRec {
+    double o[3], d[3];
+    double adist;
+    float carry[3];        // eye: path weight; photon: flux
+    uint32_t id;           // pixel index or global photon index
+    int dep, node, aobj, ainside;
+    uint32_t task_first, task_count, sub, pad;
+};
+struct NewtonTask { uint32_t park, patch; };
 
 struct SceneParams {
     const char* blob;
-    int blob_bytes, off_box, off_cp, n_objs, n_patches;
+    int blob_bytes, off_box, off_cp, off_pobj, n_objs, n_patches;
     const TexDesc* tex;
     const uchar4* texels;
 };
@@ -80,6 +91,7 @@ __device__ __forceinline__ SceneView stage_scene(const SceneParams& sp) {
     S.objs = (const DevObject*)base;
     S.patch_box = (const double*)(base + sp.off_box);
     S.patch_cp = (const float*)(base + sp.off_cp);
+    S.patch_obj = (const int*)(base + sp.off_pobj);
     S.n_objs = sp.n_objs;
     S.n_patches = sp.n_patches;
     S.tex = sp.tex;
@@ -104,103 +116,319 @@ __device__ __forceinline__ void flush_counter(unsigned long long* dst, uint32_t 
     if (lane_id() == 0 && s) atomicAdd(dst, (unsigned long long)s);
 }
 
-// ------------------------------------------------------------------ pass 1: eye trace
-struct EyeParams {
+// ------------------------------------------------------------------ path tracing: eye (pass 1) and photon (pass 2)
+// wave-aggregated allocation of n slots per lane (n may be 0); returns the lane's first slot
+__device__ __forceinline__ unsigned long long wave_alloc_n(uint32_t n, unsigned long long* counter) {
+    uint32_t inc = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t v = (uint32_t)__shfl_up((int)inc, off, 64);
+        if (lane_id() >= off) inc += v;
+    }
+    const uint32_t total = bcast_u(inc, 63);
+    if (total == 0) return 0;
+    unsigned long long base = 0;
+    if (lane_id() == 0) base = atomicAdd(counter, (unsigned long long)total);
+    base = bcast_u64(base, 0);
+    return base + (inc - n);
+}
+
+enum { MODE_EYE = 0, MODE_PHOTON = 1 };
+
+struct TraceParams {
+    // work items: [0, n_resume) = park records of the previous round, then fresh_count fresh
+    // items (pixels for the eye pass, photon indices for the photon pass)
+    const ParkRec* resume; unsigned long long n_resume;
+    const NewtonTask* tasks_in; const float4* res_in;
+    unsigned long long fresh_first, fresh_count;
+    unsigned long long* next;
+    ParkRec* park_out; unsigned long long* n_park; unsigned long long park_cap;
+    NewtonTask* tasks_out; unsigned long long* n_tasks; unsigned long long task_cap;
+    uint32_t rng;                             // rng_base(seed, replica * 4 + domain)
+    DevCounters* counters;
+    // eye pass
     double pos[3], dir[3], du[3], dv[3];
     int w, h;
-    int n_tasks;
-    const EyeTask* tasks_in;     // nullptr: primary rays from the camera
     RawHit* hits; unsigned long long* n_hits; unsigned long long hit_cap;
-    EyeTask* tasks_out; unsigned long long* n_tasks_out; unsigned long long task_cap;
-    uint32_t rng;                // rng_base(seed, replica * 4 + D_EYE)
-    DevCounters* counters;
+    // photon pass
+    const DevLight* lights; int n_lights; uint32_t per_round;
+    PosKey* depA; DepB* depB; unsigned long long* n_dep; unsigned long long dep_cap;
+    uint32_t* dcount; GridParams grid;
 };
 
-// RayTracer::GetHitPoint + ViewTrace (Raytracer.h:102-116, :296-357).  A lane follows one
-// eye path; when a material has both a reflective and a refractive lobe the refraction
-// branch is queued as a new task and traced by a follow-up launch.
-__global__ void __launch_bounds__(256) k_eye_trace(SceneParams sp, EyeParams ep) {
+// One kernel for both passes, on persistent wavefronts: a lane that finishes (or parks) its
+// path is refilled from the work counter, so lanes stay busy across paths of different length.
+//   MODE_EYE    RayTracer::GetHitPoint + ViewTrace (Raytracer.h:102-116, :296-357)
+//   MODE_PHOTON PhotonMap's emission loop + PhotonTrace (Raytracer.h:117-209, :220-233); a diffuse
+//               hit appends one deposit record (the reference's radius-search query)
+// Bezier objects: with COOP the wave solves them in place (bezier_coop).  Without, a ray whose
+// box culls leave patches to solve is PARKED: its state and one task per patch go to queues,
+// k_newton solves all tasks of the round at full occupancy, and the next launch resumes the ray
+// from its record.  This keeps the 50 x 10 Newton iterations out of the divergent path loop.
+template <int MODE, bool COOP>
+__global__ void __launch_bounds__(256, COOP ? 2 : 3) k_trace(SceneParams sp, TraceParams tp) {
     SceneView S = stage_scene(sp);
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    bool active = tid < ep.n_tasks;
+    const int lane = lane_id();
+    const unsigned long long total = tp.n_resume + tp.fresh_count;
+    bool active = false, pending = false, exhausted = (total == 0);
     d3 o = mk(0, 0, 0), d = mk(0, 0, 1);
-    float wgt[3] = {1, 1, 1};
-    int pix = 0, node = 0, dep = 0;
-    if (active) {
-        if (ep.tasks_in == nullptr) {
-            pix = tid;
-            int row = pix / ep.w, col = pix % ep.w;
-            o = ld3(ep.pos);
-            // Camera::emit(y = row, x = col), Camera.h:18-22
-            d3 dd = ld3(ep.du) * ((col + 0.5) / ep.w - 0.5) + ld3(ep.dv) * ((row + 0.5) / ep.h - 0.5) + ld3(ep.dir);
-            d = get_unit(dd);
-        } else {
-            const EyeTask t = ep.tasks_in[tid];
-            o = ld3(t.o); d = ld3(t.d);
-            wgt[0] = t.wgt[0]; wgt[1] = t.wgt[1]; wgt[2] = t.wgt[2];
-            pix = t.pix; node = t.node; dep = t.dep;
-        }
-    }
-    uint32_t ncalls = 0, nseg = 0;
-    while (__any(active)) {
-        uint32_t sub = rng_sub(ep.rng, (uint32_t)pix, (uint32_t)node, P_NEWTON);
-        Hit hit = near_collide(S, active, o, d, sub, ncalls);
-        if (active) nseg++;
-        if (active && hit.obj < 0) active = false;
-        bool emit_hp = false, push = false;
-        RawHit rh;
-        EyeTask task;
-        if (active) {
-            dep++;
-            const DevObject& ob = S.objs[hit.obj];
-            float bw[3] = {hit.color[0] * wgt[0], hit.color[1] * wgt[1], hit.color[2] * wgt[2]};
-            if (ob.flags & F_DIFF) {                                                      // Raytracer.h:312-319
-                emit_hp = true;
-                rh.pos[0] = hit.pos.x; rh.pos[1] = hit.pos.y; rh.pos[2] = hit.pos.z;
-                rh.n[0] = (float)hit.n.x; rh.n[1] = (float)hit.n.y; rh.n[2] = (float)hit.n.z;
-                rh.v[0] = (float)d.x; rh.v[1] = (float)d.y; rh.v[2] = (float)d.z;
-                rh.wgt[0] = bw[0] * ob.diff[0]; rh.wgt[1] = bw[1] * ob.diff[1]; rh.wgt[2] = bw[2] * ob.diff[2];
-                rh.pix = pix; rh.node = node; rh.obj = hit.obj;
-            }
-            const bool has_refl = ob.flags & F_REFL, has_refr = ob.flags & F_REFR;
-            d3 refl_d = mk(0, 0, 0), refr_d = mk(0, 0, 0);
-            if (has_refl) refl_d = get_unit(get_refl(d, hit.n));                          // Raytracer.h:320-326
-            if (has_refr) {                                                               // Raytracer.h:327-336
-                double refrn = hit.inside ? ob.refrn : 1 / ob.refrn;
-                refr_d = get_unit(refracted(d, hit.inside ? neg(hit.n) : hit.n, refrn));
-            }
-            if (dep > SPPM_MAX_DEP) {
-                active = false;  // the next NearCollide result would be discarded (Raytracer.h:303-309)
-            } else if (has_refl) {
-                if (has_refr) {
-                    push = true;
-                    task.o[0] = hit.pos.x; task.o[1] = hit.pos.y; task.o[2] = hit.pos.z;
-                    task.d[0] = refr_d.x; task.d[1] = refr_d.y; task.d[2] = refr_d.z;
-                    task.wgt[0] = bw[0] * ob.refr[0]; task.wgt[1] = bw[1] * ob.refr[1]; task.wgt[2] = bw[2] * ob.refr[2];
-                    task.pix = pix; task.node = 2 * node + 2; task.dep = dep;
+    float carry[3] = {0, 0, 0};
+    uint32_t id = 0, tfirst = 0, tcount = 0;
+    int dep = 0, node = 0;
+    Near nr;
+    near_init(nr);
+    uint32_t ncalls = 0, nseg = 0, ndep = 0, nphot = 0;
+    for (;;) {
+        // ---- refill idle lanes
+        const uint64_t idle = __ballot(!active);
+        if (idle && !exhausted) {
+            const unsigned long long n = (unsigned long long)__popcll(idle);
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(tp.next, n);
+            base = bcast_u64(base, 0);
+            const unsigned long long my = base + (unsigned long long)__popcll(idle & lanemask_lt());
+            if (base + n >= total) exhausted = true;
+            if (!active && my < total) {
+                active = true;
+                pending = false;
+                if (my < tp.n_resume) {
+                    const ParkRec r = tp.resume[my];
+                    o = ld3(r.o); d = ld3(r.d);
+                    carry[0] = r.carry[0]; carry[1] = r.carry[1]; carry[2] = r.carry[2];
+                    id = r.id; dep = r.dep; node = r.node;
+                    if (r.task_count) {
+                        pending = true;
+                        near_init(nr);
+                        if (r.aobj >= 0) { nr.dist = r.adist; nr.obj = r.aobj; nr.inside = r.ainside; }
+                        tfirst = r.task_first; tcount = r.task_count;
+                    }
+                } else {
+                    const unsigned long long g = tp.fresh_first + (my - tp.n_resume);
+                    id = (uint32_t)g; dep = 0; node = 0;
+                    if (MODE == MODE_EYE) {
+                        const int row = (int)(g / (unsigned long long)tp.w), col = (int)(g % (unsigned long long)tp.w);
+                        o = ld3(tp.pos);
+                        // Camera::emit(y = row, x = col), Camera.h:18-22
+                        d = get_unit(ld3(tp.du) * ((col + 0.5) / tp.w - 0.5) + ld3(tp.dv) * ((row + 0.5) / tp.h - 0.5) + ld3(tp.dir));
+                        carry[0] = carry[1] = carry[2] = 1.0f;
+                    } else {
+                        const DevLight& L = tp.lights[(g / tp.per_round) % (unsigned long long)tp.n_lights];
+                        const uint32_t es = rng_sub(tp.rng, id, 0u, P_EMIT);
+                        double x = 0, y = 0, z = 0;
+                        for (uint32_t k = 0; k < 64; k++) {                               // Vec3::GetUnitRandVec, Vec3.h:57-65
+                            x = rng_u01(es, 3 * k + 0) * 2.0 + -1.0;
+                            y = rng_u01(es, 3 * k + 1) * 2.0 + -1.0;
+                            z = rng_u01(es, 3 * k + 2) * 2.0 + -1.0;
+                            const double m = x * x + y * y + z * z;
+                            if (!(m > 1 || m < SPPM_EPS)) break;
+                        }
+                        d = get_unit(mk(x, y, z));
+                        o = ld3(L.pos);                                                   // Light::emit, Light.h:8-13
+                        carry[0] = L.flux[0]; carry[1] = L.flux[1]; carry[2] = L.flux[2];
+                        nphot++;
+                    }
                 }
-                wgt[0] = bw[0] * ob.refl[0]; wgt[1] = bw[1] * ob.refl[1]; wgt[2] = bw[2] * ob.refl[2];
-                o = hit.pos; d = refl_d; node = 2 * node + 1;
-            } else if (has_refr) {
-                wgt[0] = bw[0] * ob.refr[0]; wgt[1] = bw[1] * ob.refr[1]; wgt[2] = bw[2] * ob.refr[2];
-                o = hit.pos; d = refr_d; node = 2 * node + 2;
+            }
+        }
+        if (!__any(active)) break;
+
+        // ---- Scene::NearCollide for lanes that carry an untraced ray
+        const bool tracing = active && !pending;
+        const uint32_t sub = rng_sub(tp.rng, id, (uint32_t)(MODE == MODE_EYE ? node : dep), P_NEWTON);
+        bool park = false;
+        uint64_t words[SPPM_MASK_WORDS] = {0, 0, 0, 0};
+        if (__any(tracing)) {
+            Near a;
+            near_init(a);
+            analytic_nearest(S, tracing, o, d, a);
+            if (COOP) {
+                bezier_nearest_coop(S, tracing, o, d, sub, a, ncalls);
             } else {
+                bezier_patch_masks(S, tracing, o, d, words);
+                park = tracing && ((words[0] | words[1] | words[2] | words[3]) != 0);
+            }
+            if (tracing) nr = a;
+        }
+        // ---- lanes resumed from a park record: merge the solved patches, object by object, with
+        // the per-patch filter of Bezier.h:251-259 (tasks are in patch order)
+        if (pending) {
+            float pt = (float)SPPM_MAX_NUM, pu = 0, pv = 0;
+            int pidx = -1, cur = -1;
+            const float e = (float)SPPM_EPS;
+            for (uint32_t k = 0; k < tcount; k++) {
+                const NewtonTask tk = tp.tasks_in[tfirst + k];
+                const float4 r = tp.res_in[tfirst + k];
+                const int ob = S.patch_obj[tk.patch];
+                if (ob != cur) {
+                    if (pidx >= 0) near_consider(nr, (double)pt, cur, 0, pidx, pt, pu, pv);
+                    cur = ob; pt = (float)SPPM_MAX_NUM; pidx = -1;
+                }
+                if (r.x < e || r.x > pt || r.y < -e || r.y > 1 + e || r.z < -e || r.z > 1 + e) continue;
+                if (r.x < pt) { pt = r.x; pu = r.y; pv = r.z; pidx = (int)tk.patch; }
+            }
+            if (pidx >= 0) near_consider(nr, (double)pt, cur, 0, pidx, pt, pu, pv);
+            pending = false;
+        }
+        // ---- park rays that still need their Bezier solves
+        if (!COOP) {
+            const uint32_t my_tasks = park ? (uint32_t)(__popcll(words[0]) + __popcll(words[1]) + __popcll(words[2]) + __popcll(words[3])) : 0u;
+            const unsigned long long slot = wave_alloc(park, tp.n_park);
+            const unsigned long long tb = wave_alloc_n(my_tasks, tp.n_tasks);
+            if (park) {
+                if (slot < tp.park_cap && tb + my_tasks <= tp.task_cap) {
+                    ParkRec r;
+                    r.o[0] = o.x; r.o[1] = o.y; r.o[2] = o.z; r.d[0] = d.x; r.d[1] = d.y; r.d[2] = d.z;
+                    r.adist = nr.dist; r.aobj = nr.obj; r.ainside = nr.inside;
+                    r.carry[0] = carry[0]; r.carry[1] = carry[1]; r.carry[2] = carry[2];
+                    r.id = id; r.dep = dep; r.node = node;
+                    r.task_first = (uint32_t)tb; r.task_count = my_tasks; r.sub = sub; r.pad = 0;
+                    tp.park_out[slot] = r;
+                    uint32_t k = 0;
+#pragma unroll
+                    for (int w = 0; w < SPPM_MASK_WORDS; w++) {
+                        uint64_t m = words[w];
+                        while (m) {
+                            const int bit = __ffsll((unsigned long long)m) - 1;
+                            m &= m - 1;
+                            NewtonTask t;
+                            t.park = (uint32_t)slot; t.patch = (uint32_t)(w * 64 + bit);
+                            tp.tasks_out[tb + k++] = t;
+                        }
+                    }
+                } else {
+                    atomicOr(&tp.counters->overflow, 2u);
+                }
                 active = false;
             }
         }
-        unsigned long long slot = wave_alloc(emit_hp, ep.n_hits);
-        if (emit_hp) {
-            if (slot < ep.hit_cap) ep.hits[slot] = rh;
-            else atomicOr(&ep.counters->overflow, 1u);
-        }
-        unsigned long long tslot = wave_alloc(push, ep.n_tasks_out);
-        if (push) {
-            if (tslot < ep.task_cap) ep.tasks_out[tslot] = task;
-            else atomicOr(&ep.counters->overflow, 2u);
+
+        // ---- the hit (or miss) of every lane still active
+        Near fin = nr;
+        if (!active) near_init(fin);
+        const Hit hit = finish_hit(S, o, d, fin);
+        if (active) nseg++;
+        if (active && hit.obj < 0) active = false;
+
+        if (MODE == MODE_EYE) {
+            bool emit_hp = false, push = false;
+            RawHit rh;
+            ParkRec br;
+            if (active) {
+                dep++;
+                const DevObject& ob = S.objs[hit.obj];
+                const float bw[3] = {hit.color[0] * carry[0], hit.color[1] * carry[1], hit.color[2] * carry[2]};
+                if (ob.flags & F_DIFF) {                                                  // Raytracer.h:312-319
+                    emit_hp = true;
+                    rh.pos[0] = hit.pos.x; rh.pos[1] = hit.pos.y; rh.pos[2] = hit.pos.z;
+                    rh.n[0] = (float)hit.n.x; rh.n[1] = (float)hit.n.y; rh.n[2] = (float)hit.n.z;
+                    rh.v[0] = (float)d.x; rh.v[1] = (float)d.y; rh.v[2] = (float)d.z;
+                    rh.wgt[0] = bw[0] * ob.diff[0]; rh.wgt[1] = bw[1] * ob.diff[1]; rh.wgt[2] = bw[2] * ob.diff[2];
+                    rh.pix = (int)id; rh.node = node; rh.obj = hit.obj;
+                }
+                const bool has_refl = ob.flags & F_REFL, has_refr = ob.flags & F_REFR;
+                d3 refl_d = mk(0, 0, 0), refr_d = mk(0, 0, 0);
+                if (has_refl) refl_d = get_unit(get_refl(d, hit.n));                      // Raytracer.h:320-326
+                if (has_refr) {                                                           // Raytracer.h:327-336
+                    const double refrn = hit.inside ? ob.refrn : 1 / ob.refrn;
+                    refr_d = get_unit(refracted(d, hit.inside ? neg(hit.n) : hit.n, refrn));
+                }
+                if (dep > SPPM_MAX_DEP) {
+                    active = false;  // the next NearCollide result would be discarded (Raytracer.h:303-309)
+                } else if (has_refl) {
+                    if (has_refr) {  // both lobes: the refraction branch becomes a fresh parked ray
+                        push = true;
+                        br.o[0] = hit.pos.x; br.o[1] = hit.pos.y; br.o[2] = hit.pos.z;
+                        br.d[0] = refr_d.x; br.d[1] = refr_d.y; br.d[2] = refr_d.z;
+                        br.carry[0] = bw[0] * ob.refr[0]; br.carry[1] = bw[1] * ob.refr[1]; br.carry[2] = bw[2] * ob.refr[2];
+                        br.id = id; br.dep = dep; br.node = 2 * node + 2;
+                        br.adist = 0; br.aobj = -1; br.ainside = 0; br.task_first = 0; br.task_count = 0; br.sub = 0; br.pad = 0;
+                    }
+                    carry[0] = bw[0] * ob.refl[0]; carry[1] = bw[1] * ob.refl[1]; carry[2] = bw[2] * ob.refl[2];
+                    o = hit.pos; d = refl_d; node = 2 * node + 1;
+                } else if (has_refr) {
+                    carry[0] = bw[0] * ob.refr[0]; carry[1] = bw[1] * ob.refr[1]; carry[2] = bw[2] * ob.refr[2];
+                    o = hit.pos; d = refr_d; node = 2 * node + 2;
+                } else {
+                    active = false;
+                }
+            }
+            const unsigned long long hs = wave_alloc(emit_hp, tp.n_hits);
+            if (emit_hp) {
+                if (hs < tp.hit_cap) tp.hits[hs] = rh;
+                else atomicOr(&tp.counters->overflow, 1u);
+            }
+            const unsigned long long bs = wave_alloc(push, tp.n_park);
+            if (push) {
+                if (bs < tp.park_cap) tp.park_out[bs] = br;
+                else atomicOr(&tp.counters->overflow, 2u);
+            }
+        } else {
+            bool dp = false;
+            PosKey da;
+            DepB db;
+            if (active) {
+                const uint32_t vertex = (uint32_t)dep;
+                dep++;
+                const DevObject& ob = S.objs[hit.obj];
+                if (ob.flags & F_DIFF) {                                                  // Raytracer.h:136-160: the gather query
+                    dp = true;
+                    da.x = hit.pos.x; da.y = hit.pos.y; da.z = hit.pos.z;
+                    da.key = cell_key(hit.pos, tp.grid.inv_cs);
+                    db.nx = (float)hit.n.x; db.ny = (float)hit.n.y; db.nz = (float)hit.n.z;
+                    db.fr = carry[0]; db.fg = carry[1]; db.fb = carry[2];
+                    db.bucket = key_bucket(da.key, tp.grid.mask) | (vertex << 24); db.photon = id;
+                }
+                // Obj::Roulette, Obj.h:30-45
+                const double r = rng_u01(rng_sub(tp.rng, id, vertex, P_ROULETTE), 0) * ob.allr;
+                d3 nd;
+                if (ob.diffr > r) {                                                       // DIFF, Raytracer.h:163-166
+                    const uint32_t ds = rng_sub(tp.rng, id, vertex, P_DIFFUSE);
+                    nd = rand_refl(hit.n, rng_u01(ds, 0), rng_u01(ds, 1));
+                } else if (ob.diffr + ob.reflr > r) {                                     // REFL, Raytracer.h:177-181
+                    nd = get_unit(get_refl(d, hit.n));
+                } else {                                                                  // REFR, Raytracer.h:182-190
+                    const double refrn = hit.inside ? ob.refrn : 1 / ob.refrn;
+                    nd = get_unit(refracted(d, hit.inside ? neg(hit.n) : hit.n, refrn));
+                }
+                carry[0] *= hit.color[0]; carry[1] *= hit.color[1]; carry[2] *= hit.color[2];
+                o = hit.pos; d = nd;
+                if (dep > SPPM_MAX_DEP) active = false;                                   // Raytracer.h:126-133
+            }
+            const unsigned long long slot = wave_alloc(dp, tp.n_dep);
+            if (dp) {
+                ndep++;
+                if (slot < tp.dep_cap) {
+                    tp.depA[slot] = da; tp.depB[slot] = db;
+                    atomicAdd(&tp.dcount[db.bucket & 0xffffffu], 1u);
+                } else atomicOr(&tp.counters->overflow, 4u);
+            }
         }
     }
-    flush_counter(&ep.counters->newton_calls, ncalls);
-    flush_counter(&ep.counters->eye_segments, nseg);
+    flush_counter(&tp.counters->newton_calls, ncalls);
+    if (MODE == MODE_EYE) {
+        flush_counter(&tp.counters->eye_segments, nseg);
+    } else {
+        flush_counter(&tp.counters->segments, nseg);
+        flush_counter(&tp.counters->deposits, ndep);
+        flush_counter(&tp.counters->photons, nphot);
+    }
+}
+
+// Bezier3::newton (Bezier.h:112-159) for every task of a round: one wave per (ray, patch),
+// lane r < 50 = restart r, control points read from global memory with a wave-uniform address.
+__global__ void __launch_bounds__(256) k_newton(const ParkRec* __restrict__ park, const NewtonTask* __restrict__ tasks, uint32_t n_tasks,
+                                                const float* __restrict__ patches, float4* __restrict__ res, DevCounters* counters) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    uint32_t done = 0;
+    for (uint32_t t = wave; t < n_tasks; t += n_waves) {
+        const uint32_t pk = __builtin_amdgcn_readfirstlane(tasks[t].park), patch = __builtin_amdgcn_readfirstlane(tasks[t].patch);
+        const ParkRec& r = park[pk];
+        const f3 fo = {(float)r.o[0], (float)r.o[1], (float)r.o[2]}, fd = {(float)r.d[0], (float)r.d[1], (float)r.d[2]};
+        float rt, ru, rv;
+        newton_coop(patches, (int)patch, fo, fd, r.sub, rt, ru, rv);
+        if (lane_id() == 0) { res[t] = make_float4(rt, ru, rv, 0.0f); done++; }
+    }
+    flush_counter(&counters->newton_calls, done);
 }
 
 // ------------------------------------------------------------------ hashed grid over HitPoints
@@ -284,109 +512,6 @@ __global__ void k_hp_scatter(const RawHit* hits, uint32_t n, GridParams g, const
     hp_tao[s] = make_float4(0, 0, 0, __int_as_float(0));                                  // tao = 0, newN = 0
     HpMeta m; m.v[0] = h.v[0]; m.v[1] = h.v[1]; m.v[2] = h.v[2]; m.node = h.node; m.obj = h.obj; m.N = 0;
     hp_meta[s] = m;
-}
-
-// ------------------------------------------------------------------ pass 2: photon trace
-struct PhotonParams {
-    const DevLight* lights; int n_lights; uint32_t per_round;
-    unsigned long long first, count;          // this batch: global photon indices [first, first + count)
-    unsigned long long* next;                 // batch-relative photon counter
-    PosKey* depA; DepB* depB; unsigned long long* n_dep; unsigned long long dep_cap;
-    uint32_t* dcount; GridParams grid;
-    uint32_t rng;                             // rng_base(seed, replica * 4 + D_PHOTON)
-    DevCounters* counters;
-};
-
-// RayTracer::PhotonMap's emission loop + PhotonTrace (Raytracer.h:117-209, :220-233) on
-// persistent wavefronts: a lane that finishes its photon is refilled from the photon
-// counter, so lanes stay busy across paths of different length.  A diffuse hit appends one
-// deposit record (the reference's radius-search query) instead of searching inline.
-__global__ void __launch_bounds__(256) k_photon_trace(SceneParams sp, PhotonParams pp) {
-    SceneView S = stage_scene(sp);
-    const int lane = lane_id();
-    bool active = false, exhausted = false;
-    d3 o = mk(0, 0, 0), d = mk(0, 0, 1);
-    float flux[3] = {0, 0, 0};
-    int dep = 0;
-    uint32_t pid = 0;
-    uint32_t ncalls = 0, nseg = 0, ndep = 0, nphot = 0;
-    for (;;) {
-        uint64_t idle = __ballot(!active);
-        if (idle && !exhausted) {
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(pp.next, (unsigned long long)__popcll(idle));
-            base = bcast_u64(base, 0);
-            unsigned long long my = base + (unsigned long long)__popcll(idle & lanemask_lt());
-            if (base + (unsigned long long)__popcll(idle) >= pp.count) exhausted = true;
-            if (!active && my < pp.count) {
-                unsigned long long g = pp.first + my;
-                const DevLight& L = pp.lights[(g / pp.per_round) % (unsigned long long)pp.n_lights];
-                pid = (uint32_t)g;
-                uint32_t es = rng_sub(pp.rng, pid, 0u, P_EMIT);
-                double x = 0, y = 0, z = 0;
-                for (uint32_t k = 0; k < 64; k++) {                                       // Vec3::GetUnitRandVec, Vec3.h:57-65
-                    x = rng_u01(es, 3 * k + 0) * 2.0 + -1.0;
-                    y = rng_u01(es, 3 * k + 1) * 2.0 + -1.0;
-                    z = rng_u01(es, 3 * k + 2) * 2.0 + -1.0;
-                    double m = x * x + y * y + z * z;
-                    if (!(m > 1 || m < SPPM_EPS)) break;
-                }
-                d = get_unit(mk(x, y, z));
-                o = ld3(L.pos);                                                           // Light::emit, Light.h:8-13
-                flux[0] = L.flux[0]; flux[1] = L.flux[1]; flux[2] = L.flux[2];
-                dep = 0;
-                active = true;
-                nphot++;
-            }
-        }
-        if (!__any(active)) break;
-        uint32_t sub = rng_sub(pp.rng, pid, (uint32_t)dep, P_NEWTON);
-        Hit hit = near_collide(S, active, o, d, sub, ncalls);
-        if (active) nseg++;
-        if (active && hit.obj < 0) active = false;
-        bool dp = false;
-        PosKey da; DepB db;
-        if (active) {
-            const uint32_t vertex = (uint32_t)dep;
-            dep++;
-            const DevObject& ob = S.objs[hit.obj];
-            if (ob.flags & F_DIFF) {                                                      // Raytracer.h:136-160: the gather query
-                dp = true;
-                da.x = hit.pos.x; da.y = hit.pos.y; da.z = hit.pos.z;
-                da.key = cell_key(hit.pos, pp.grid.inv_cs);
-                db.nx = (float)hit.n.x; db.ny = (float)hit.n.y; db.nz = (float)hit.n.z;
-                db.fr = flux[0]; db.fg = flux[1]; db.fb = flux[2];
-                db.bucket = key_bucket(da.key, pp.grid.mask) | (vertex << 24); db.photon = pid;
-            }
-            // Obj::Roulette, Obj.h:30-45
-            double r = rng_u01(rng_sub(pp.rng, pid, vertex, P_ROULETTE), 0) * ob.allr;
-            d3 nd;
-            if (ob.diffr > r) {                                                           // DIFF, Raytracer.h:163-166
-                uint32_t ds = rng_sub(pp.rng, pid, vertex, P_DIFFUSE);
-                nd = rand_refl(hit.n, rng_u01(ds, 0), rng_u01(ds, 1));
-            } else if (ob.diffr + ob.reflr > r) {                                         // REFL, Raytracer.h:177-181
-                nd = get_unit(get_refl(d, hit.n));
-            } else {                                                                      // REFR, Raytracer.h:182-190
-                double refrn = hit.inside ? ob.refrn : 1 / ob.refrn;
-                nd = get_unit(refracted(d, hit.inside ? neg(hit.n) : hit.n, refrn));
-            }
-            flux[0] *= hit.color[0]; flux[1] *= hit.color[1]; flux[2] *= hit.color[2];
-            o = hit.pos; d = nd;
-            if (dep > SPPM_MAX_DEP) active = false;                                       // Raytracer.h:126-133
-        }
-        unsigned long long slot = wave_alloc(dp, pp.n_dep);
-        if (dp) {
-            ndep++;
-            if (slot < pp.dep_cap) {
-                pp.depA[slot] = da; pp.depB[slot] = db;
-                atomicAdd(&pp.dcount[db.bucket & 0xffffffu], 1u);
-            } else atomicOr(&pp.counters->overflow, 4u);
-        }
-    }
-    flush_counter(&pp.counters->newton_calls, ncalls);
-    flush_counter(&pp.counters->segments, nseg);
-    flush_counter(&pp.counters->deposits, ndep);
-    flush_counter(&pp.counters->photons, nphot);
 }
 
 __global__ void k_dep_scatter(const PosKey* depA, const DepB* depB, const unsigned long long* n_dep, unsigned long long cap,
@@ -582,13 +707,17 @@ struct sppm_ctx {
     std::string err;
     // scene
     bool have_scene = false;
-    DevBuf<char> blob; int blob_bytes = 0, off_box = 0, off_cp = 0, n_objs = 0, n_patches = 0;
+    DevBuf<char> blob; int blob_bytes = 0, off_box = 0, off_cp = 0, off_pobj = 0, n_objs = 0, n_patches = 0;
     DevBuf<TexDesc> tex; DevBuf<uchar4> texels;
     DevBuf<DevLight> lights; int n_lights = 0;
     // eye pass
     bool have_eye = false;
     sppm_camera cam{};
-    DevBuf<RawHit> raw; DevBuf<EyeTask> tasks[2];
+    DevBuf<RawHit> raw;
+    DevBuf<ParkRec> park[2]; DevBuf<NewtonTask> ntask[2]; DevBuf<float4> nres;
+    uint64_t coop_threshold = 4096;   // rounds with fewer parked rays finish inside the trace kernel
+    bool force_coop = false;
+    bool verbose = false;
     DevBuf<uint32_t> bucket_of, hcount, hstart, cursor;
     DevBuf<PosKey> hp_pos; DevBuf<float4> hp_nr, hp_wgt, hp_tao; DevBuf<HpMeta> hp_meta;
     uint64_t n_hp = 0;
@@ -607,7 +736,7 @@ struct sppm_ctx {
 
     SceneParams scene_params() const {
         SceneParams sp;
-        sp.blob = blob.p; sp.blob_bytes = blob_bytes; sp.off_box = off_box; sp.off_cp = off_cp;
+        sp.blob = blob.p; sp.blob_bytes = blob_bytes; sp.off_box = off_box; sp.off_cp = off_cp; sp.off_pobj = off_pobj;
         sp.n_objs = n_objs; sp.n_patches = n_patches; sp.tex = tex.p; sp.texels = texels.p;
         return sp;
     }
@@ -667,6 +796,9 @@ int sppm_create(sppm_ctx** out, int device_id) {
         long long v = atoll(b);
         if (v > 0) ctx->batch = (uint64_t)v;
     }
+    if (const char* b = getenv("SPPM_COOP_THRESHOLD")) ctx->coop_threshold = (uint64_t)std::max(0ll, atoll(b));
+    if (const char* b = getenv("SPPM_FORCE_COOP")) ctx->force_coop = atoi(b) != 0;
+    if (const char* b = getenv("SPPM_VERBOSE")) ctx->verbose = atoi(b) != 0;
     if (ctx->scalars.reserve(8) != hipSuccess || ctx->counters.reserve(1) != hipSuccess) {
         delete ctx;
         return SPPM_E_DEVICE;
@@ -681,7 +813,7 @@ void sppm_destroy(sppm_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->blob.release(); ctx->tex.release(); ctx->texels.release(); ctx->lights.release();
-    ctx->raw.release(); ctx->tasks[0].release(); ctx->tasks[1].release();
+    ctx->raw.release(); ctx->park[0].release(); ctx->park[1].release(); ctx->ntask[0].release(); ctx->ntask[1].release(); ctx->nres.release();
     ctx->bucket_of.release(); ctx->hcount.release(); ctx->hstart.release(); ctx->cursor.release();
     ctx->hp_pos.release(); ctx->hp_nr.release(); ctx->hp_wgt.release(); ctx->hp_tao.release(); ctx->hp_meta.release();
     ctx->depA.release(); ctx->sdepA.release(); ctx->depB.release(); ctx->sdepB.release();
@@ -705,12 +837,16 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
     const int no = s->n_objects, np = s->n_patches;
     const int off_box = (int)(((size_t)no * sizeof(DevObject) + 15) & ~(size_t)15);
     const int off_cp = off_box + np * 6 * (int)sizeof(double);
-    const int bytes = off_cp + np * 48 * (int)sizeof(float);
+    const int off_pobj = off_cp + np * 48 * (int)sizeof(float);
+    const int bytes = (off_pobj + np * (int)sizeof(int) + 15) & ~15;
+    if (np > 64 * SPPM_MASK_WORDS) return fail(ctx, SPPM_E_CAPACITY, "more than 256 Bezier patches in one scene");
     if (bytes > 64 * 1024) return fail(ctx, SPPM_E_CAPACITY, "scene tables exceed the 64 KiB LDS staging area (too many patches/objects)");
     std::vector<char> blob((size_t)bytes, 0);
     DevObject* objs = (DevObject*)blob.data();
     double* box = (double*)(blob.data() + off_box);
     float* cp = (float*)(blob.data() + off_cp);
+    int* pobj = (int*)(blob.data() + off_pobj);
+    for (int p = 0; p < np; p++) pobj[p] = -1;
     for (int p = 0; p < np; p++) {                                                       // Bezier3::read, Bezier.h:167-175
         double* b = box + 6 * p;
         for (int k = 0; k < 3; k++) { b[k] = 1e20; b[3 + k] = -1e20; }
@@ -746,16 +882,19 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
         if (so.type == SPPM_OBJ_BEZIER) {
             if (so.first_patch < 0 || so.n_patches < 0 || so.first_patch + so.n_patches > np)
                 return fail(ctx, SPPM_E_INVALID, "bezier object indexes patches out of range");
-            for (int p = so.first_patch; p < so.first_patch + so.n_patches; p++)           // Bezier.h:226-231
+            for (int p = so.first_patch; p < so.first_patch + so.n_patches; p++) {         // Bezier.h:226-231
+                if (pobj[p] >= 0) return fail(ctx, SPPM_E_INVALID, "two bezier objects share a patch");
+                pobj[p] = i;
                 for (int k = 0; k < 3; k++) {
                     o.bmin[k] = std::min(o.bmin[k], box[6 * p + k]);
                     o.bmax[k] = std::max(o.bmax[k], box[6 * p + 3 + k]);
                 }
+            }
         }
     }
     HIPCHK(ctx->blob.reserve((size_t)bytes));
     HIPCHK(hipMemcpy(ctx->blob.p, blob.data(), (size_t)bytes, hipMemcpyHostToDevice));
-    ctx->blob_bytes = bytes; ctx->off_box = off_box; ctx->off_cp = off_cp; ctx->n_objs = no; ctx->n_patches = np;
+    ctx->blob_bytes = bytes; ctx->off_box = off_box; ctx->off_cp = off_cp; ctx->off_pobj = off_pobj; ctx->n_objs = no; ctx->n_patches = np;
     // textures -> packed uchar4
     std::vector<TexDesc> td((size_t)std::max(1, s->n_textures));
     size_t total = 0;
@@ -809,60 +948,111 @@ static int launch_scan(sppm_ctx* ctx, const uint32_t* cnt, uint32_t* start, uint
     return SPPM_OK;
 }
 
+}  // extern "C" (templates below need C++ linkage)
+
+// scalars: device-side counters shared by the passes
+enum { SC_HITS = 0, SC_NEXT = 2, SC_DEP = 3, SC_PARK0 = 4, SC_TASK0 = 5, SC_PARK1 = 6, SC_TASK1 = 7 };
+
+template <int MODE>
+static void launch_trace(sppm_ctx* ctx, bool coop, int blocks, const SceneParams& sp, const TraceParams& tp) {
+    if (coop) hipLaunchKernelGGL((k_trace<MODE, true>), dim3(blocks), dim3(256), (size_t)ctx->blob_bytes, ctx->stream, sp, tp);
+    else hipLaunchKernelGGL((k_trace<MODE, false>), dim3(blocks), dim3(256), (size_t)ctx->blob_bytes, ctx->stream, sp, tp);
+}
+
+// Runs one set of fresh work items (pixels or photons) to completion: trace -> [newton ->
+// resume trace]* until no ray is parked.  tp carries the pass-specific outputs.
+static int run_rounds(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_first, uint64_t fresh_count, int* launches) {
+    const uint64_t park_cap = std::max<uint64_t>(fresh_count, 1u << 16);
+    const uint64_t task_cap = 16 * park_cap;
+    if (task_cap > 0xffffffffull) return fail(ctx, SPPM_E_CAPACITY, "too many work items for one round");
+    HIPCHK(ctx->park[0].reserve(park_cap)); HIPCHK(ctx->park[1].reserve(park_cap));
+    HIPCHK(ctx->ntask[0].reserve(task_cap)); HIPCHK(ctx->ntask[1].reserve(task_cap));
+    HIPCHK(ctx->nres.reserve(task_cap));
+    const SceneParams sp = ctx->scene_params();
+    unsigned long long* sc = ctx->scalars.p;
+    HIPCHK(hipMemsetAsync(sc + SC_NEXT, 0, sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(sc + SC_PARK0, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    tp.next = sc + SC_NEXT;
+    tp.park_cap = park_cap; tp.task_cap = task_cap;
+    tp.resume = nullptr; tp.n_resume = 0; tp.tasks_in = nullptr; tp.res_in = nullptr;
+    tp.fresh_first = fresh_first; tp.fresh_count = fresh_count;
+    const int max_blocks = ctx->num_cu * 4;
+    auto blocks_for = [&](uint64_t items) { return (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)max_blocks, (items + 255) / 256)); };
+    int cur = 0;
+    tp.park_out = ctx->park[0].p; tp.n_park = sc + SC_PARK0; tp.tasks_out = ctx->ntask[0].p; tp.n_tasks = sc + SC_TASK0;
+    bool coop = ctx->force_coop;
+    if (mode == MODE_EYE) launch_trace<MODE_EYE>(ctx, coop, blocks_for(fresh_count), sp, tp);
+    else launch_trace<MODE_PHOTON>(ctx, coop, blocks_for(fresh_count), sp, tp);
+    HIPCHK(hipGetLastError());
+    if (launches) (*launches)++;
+    for (int round = 0; round < 256; round++) {
+        unsigned long long q[2];
+        DevCounters dc;
+        HIPCHK(hipMemcpyAsync(q, sc + (cur ? SC_PARK1 : SC_PARK0), sizeof(q), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(&dc, ctx->counters.p, sizeof(dc), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (dc.overflow & 1u) return SPPM_E_CAPACITY + 100;   // HitPoint buffer too small: the caller retries with more room
+        if (dc.overflow & 6u) return fail(ctx, SPPM_E_CAPACITY, "a ray / task / deposit queue overflowed");
+        const unsigned long long n_park = q[0], n_tasks = q[1];
+        if (ctx->verbose) fprintf(stderr, "[sppm] mode %d round %d: parked %llu rays, %llu newton tasks\n", mode, round, n_park, n_tasks);
+        if (n_park == 0) return SPPM_OK;
+        if (n_tasks > 0) {
+            const int nb = (int)std::min<uint64_t>((n_tasks + 3) / 4, (uint64_t)ctx->num_cu * 32);
+            hipLaunchKernelGGL(k_newton, dim3(nb), dim3(256), 0, ctx->stream, ctx->park[cur].p, ctx->ntask[cur].p, (uint32_t)n_tasks,
+                               (const float*)(ctx->blob.p + ctx->off_cp), ctx->nres.p, ctx->counters.p);
+        }
+        const int nxt = cur ^ 1;
+        HIPCHK(hipMemsetAsync(sc + SC_NEXT, 0, sizeof(unsigned long long), ctx->stream));
+        HIPCHK(hipMemsetAsync(sc + (nxt ? SC_PARK1 : SC_PARK0), 0, 2 * sizeof(unsigned long long), ctx->stream));
+        tp.resume = ctx->park[cur].p; tp.n_resume = n_park; tp.tasks_in = ctx->ntask[cur].p; tp.res_in = ctx->nres.p;
+        tp.fresh_first = 0; tp.fresh_count = 0;
+        tp.park_out = ctx->park[nxt].p; tp.n_park = sc + (nxt ? SC_PARK1 : SC_PARK0);
+        tp.tasks_out = ctx->ntask[nxt].p; tp.n_tasks = sc + (nxt ? SC_TASK1 : SC_TASK0);
+        coop = ctx->force_coop || n_park < ctx->coop_threshold;
+        if (mode == MODE_EYE) launch_trace<MODE_EYE>(ctx, coop, blocks_for(n_park), sp, tp);
+        else launch_trace<MODE_PHOTON>(ctx, coop, blocks_for(n_park), sp, tp);
+        HIPCHK(hipGetLastError());
+        if (launches) (*launches)++;
+        cur = nxt;
+    }
+    return fail(ctx, SPPM_E_DEVICE, "trace rounds did not drain");
+}
+
+extern "C" {
+
 int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t replica) {
     if (!ctx || !cam) return SPPM_E_INVALID;
     if (!ctx->have_scene) return fail(ctx, SPPM_E_INVALID, "sppm_set_scene must come first");
-    if (cam->w <= 0 || cam->h <= 0 || (uint64_t)cam->w * cam->h > (1ull << 30)) return fail(ctx, SPPM_E_INVALID, "bad resolution");
+    if (cam->w <= 0 || cam->h <= 0 || (uint64_t)cam->w * cam->h > (1ull << 28)) return fail(ctx, SPPM_E_INVALID, "bad resolution");
     HIPCHK(hipSetDevice(ctx->device));
     ctx->cam = *cam;
     ctx->have_eye = false;
     const uint64_t npx = (uint64_t)cam->w * cam->h;
     uint64_t hit_cap = std::max<uint64_t>(2 * npx, 1 << 16);
-    uint64_t task_cap = std::max<uint64_t>(npx, 1 << 16);
-    SceneParams sp = ctx->scene_params();
     ctx->tm = sppm_timings{};
-    for (int attempt = 0; attempt < 6; attempt++) {
+    for (int attempt = 0;; attempt++) {
         HIPCHK(ctx->raw.reserve(hit_cap));
-        HIPCHK(ctx->tasks[0].reserve(task_cap));
-        HIPCHK(ctx->tasks[1].reserve(task_cap));
         HIPCHK(hipMemsetAsync(ctx->scalars.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->counters.p, 0, sizeof(DevCounters), ctx->stream));
         tic(ctx);
-        EyeParams ep;
-        for (int k = 0; k < 3; k++) { ep.pos[k] = cam->pos[k]; ep.dir[k] = cam->dir[k]; ep.du[k] = cam->du[k]; ep.dv[k] = cam->dv[k]; }
-        ep.w = cam->w; ep.h = cam->h;
-        ep.hits = ctx->raw.p; ep.n_hits = ctx->scalars.p + 0; ep.hit_cap = hit_cap;
-        ep.n_tasks_out = ctx->scalars.p + 1; ep.task_cap = task_cap;
-        ep.counters = ctx->counters.p;
-        ep.rng = host_rng_base(seed, replica * 4u + D_EYE);
-        uint64_t n_tasks = npx;
-        const EyeTask* in = nullptr;
-        int cur = 0, launches = 0;
-        bool overflow = false;
-        while (n_tasks > 0) {
-            ep.n_tasks = (int)n_tasks; ep.tasks_in = in; ep.tasks_out = ctx->tasks[cur].p;
-            HIPCHK(hipMemsetAsync(ctx->scalars.p + 1, 0, sizeof(unsigned long long), ctx->stream));
-            int blocks = (int)((n_tasks + 255) / 256);
-            hipLaunchKernelGGL(k_eye_trace, dim3(blocks), dim3(256), (size_t)ctx->blob_bytes, ctx->stream, sp, ep);
-            HIPCHK(hipGetLastError());
-            launches++;
-            unsigned long long sc[2];
-            HIPCHK(hipMemcpyAsync(sc, ctx->scalars.p, sizeof(sc), hipMemcpyDeviceToHost, ctx->stream));
-            DevCounters dc;
-            HIPCHK(hipMemcpyAsync(&dc, ctx->counters.p, sizeof(dc), hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));
-            if (dc.overflow) { overflow = true; break; }
-            n_tasks = sc[1];
-            in = ctx->tasks[cur].p;
-            cur ^= 1;
-            ctx->n_hp = sc[0];
-        }
+        TraceParams tp{};
+        for (int k = 0; k < 3; k++) { tp.pos[k] = cam->pos[k]; tp.dir[k] = cam->dir[k]; tp.du[k] = cam->du[k]; tp.dv[k] = cam->dv[k]; }
+        tp.w = cam->w; tp.h = cam->h;
+        tp.hits = ctx->raw.p; tp.n_hits = ctx->scalars.p + SC_HITS; tp.hit_cap = hit_cap;
+        tp.counters = ctx->counters.p;
+        tp.rng = host_rng_base(seed, replica * 4u + D_EYE);
+        int launches = 0;
+        const int rc = run_rounds(ctx, MODE_EYE, tp, 0, npx, &launches);
         ctx->tm.eye_trace_ms = toc(ctx);
         ctx->tm.trace_launches = launches;
-        if (!overflow) break;
-        if (attempt == 5) return fail(ctx, SPPM_E_CAPACITY, "eye pass queues overflowed after 5 capacity doublings");
-        hit_cap *= 2; task_cap *= 2;
+        if (rc == SPPM_OK) break;
+        if (rc != SPPM_E_CAPACITY + 100) return rc;
+        if (attempt == 5) return fail(ctx, SPPM_E_CAPACITY, "HitPoint buffer overflowed after 5 capacity doublings");
+        hit_cap *= 2;
     }
+    unsigned long long nh = 0;
+    HIPCHK(hipMemcpy(&nh, ctx->scalars.p + SC_HITS, sizeof(nh), hipMemcpyDeviceToHost));
+    ctx->n_hp = nh;
     // ---- hashed grid over HitPoints
     const uint64_t n = ctx->n_hp;
     const double cs = std::sqrt(SPPM_INIT_R2) * 1.0001;   // cell >= search radius: neighbours within +-1 cell
@@ -892,6 +1082,14 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
     return SPPM_OK;
 }
 
+static void fill_photon_params(sppm_ctx* ctx, TraceParams& tp, uint32_t per_round, uint64_t dep_cap, uint64_t seed, uint32_t replica,
+                               DevCounters* counters) {
+    tp.lights = ctx->lights.p; tp.n_lights = ctx->n_lights; tp.per_round = per_round;
+    tp.depA = ctx->depA.p; tp.depB = ctx->depB.p; tp.n_dep = ctx->scalars.p + SC_DEP; tp.dep_cap = dep_cap;
+    tp.dcount = ctx->dcount.p; tp.grid = ctx->grid; tp.counters = counters;
+    tp.rng = host_rng_base(seed, replica * 4u + D_PHOTON);
+}
+
 int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_t photon_begin, uint64_t photon_count,
                      uint64_t seed, uint32_t replica) {
     if (!ctx) return SPPM_E_INVALID;
@@ -904,33 +1102,25 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
     const uint64_t end = photon_count == 0 ? total : std::min(total, photon_begin + photon_count);
     ctx->last_rounds = rounds; ctx->last_per_round = per_round;
     const uint32_t M = ctx->grid.mask + 1;
-    SceneParams sp = ctx->scene_params();
-    PhotonParams pp;
-    pp.lights = ctx->lights.p; pp.n_lights = ctx->n_lights; pp.per_round = per_round;
-    pp.next = ctx->scalars.p + 2; pp.n_dep = ctx->scalars.p + 3;
-    pp.dcount = ctx->dcount.p; pp.grid = ctx->grid; pp.counters = ctx->counters.p;
-    pp.rng = host_rng_base(seed, replica * 4u + D_PHOTON);
     const uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(ctx->batch, end > photon_begin ? end - photon_begin : 1));
     const uint64_t dep_cap = batch * (SPPM_MAX_DEP + 1);
     HIPCHK(ctx->depA.reserve(dep_cap)); HIPCHK(ctx->depB.reserve(dep_cap));
     HIPCHK(ctx->sdepA.reserve(dep_cap)); HIPCHK(ctx->sdepB.reserve(dep_cap));
-    pp.depA = ctx->depA.p; pp.depB = ctx->depB.p; pp.dep_cap = dep_cap;
-    const int trace_blocks = ctx->num_cu * 4;
+    TraceParams tp{};
+    fill_photon_params(ctx, tp, per_round, dep_cap, seed, replica, ctx->counters.p);
     ctx->tm.photon_trace_ms = ctx->tm.deposit_sort_ms = ctx->tm.gather_ms = 0;
     ctx->tm.gather_launches = 0;
     for (uint64_t first = photon_begin; first < end; first += batch) {
         const uint64_t count = std::min(batch, end - first);
-        pp.first = first; pp.count = count;
-        HIPCHK(hipMemsetAsync(ctx->scalars.p + 2, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->scalars.p + SC_DEP, 0, sizeof(unsigned long long), ctx->stream));
         if (int rc = launch_fill(ctx, ctx->dcount.p, M + 1, 0)) return rc;
         if (int rc = launch_fill(ctx, ctx->cursor.p, M + 1, 0)) return rc;
         tic(ctx);
-        hipLaunchKernelGGL(k_photon_trace, dim3(trace_blocks), dim3(256), (size_t)ctx->blob_bytes, ctx->stream, sp, pp);
-        HIPCHK(hipGetLastError());
+        if (int rc = run_rounds(ctx, MODE_PHOTON, tp, first, count, nullptr)) return rc;
         ctx->tm.photon_trace_ms += toc(ctx);
         tic(ctx);
         if (int rc = launch_scan(ctx, ctx->dcount.p, ctx->dstart.p, M)) return rc;
-        hipLaunchKernelGGL(k_dep_scatter, dim3(ctx->num_cu * 8), dim3(256), 0, ctx->stream, ctx->depA.p, ctx->depB.p, ctx->scalars.p + 3,
+        hipLaunchKernelGGL(k_dep_scatter, dim3(ctx->num_cu * 8), dim3(256), 0, ctx->stream, ctx->depA.p, ctx->depB.p, ctx->scalars.p + SC_DEP,
                            dep_cap, ctx->dstart.p, ctx->cursor.p, ctx->sdepA.p, ctx->sdepB.p);
         HIPCHK(hipGetLastError());
         ctx->tm.deposit_sort_ms += toc(ctx);
@@ -945,10 +1135,7 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
             ctx->tm.gather_launches++;
         }
     }
-    DevCounters dc;
-    HIPCHK(hipMemcpyAsync(&dc, ctx->counters.p, sizeof(dc), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (dc.overflow & 4u) return fail(ctx, SPPM_E_CAPACITY, "deposit queue overflowed");
     return SPPM_OK;
 }
 
@@ -1071,20 +1258,19 @@ int sppm_debug_photon_deposits(sppm_ctx* ctx, uint64_t rounds, uint32_t per_roun
     DevBuf<DevCounters> scratch_counters;   // keep the pass counters untouched
     HIPCHK(scratch_counters.reserve(1));
     HIPCHK(hipMemsetAsync(scratch_counters.p, 0, sizeof(DevCounters), ctx->stream));
-    PhotonParams pp;
-    pp.lights = ctx->lights.p; pp.n_lights = ctx->n_lights; pp.per_round = per_round;
-    pp.first = photon_begin; pp.count = count;
-    pp.next = ctx->scalars.p + 2; pp.n_dep = ctx->scalars.p + 3;
-    pp.depA = ctx->depA.p; pp.depB = ctx->depB.p; pp.dep_cap = dep_cap;
-    pp.dcount = ctx->dcount.p; pp.grid = ctx->grid; pp.counters = scratch_counters.p;
-    pp.rng = host_rng_base(seed, replica * 4u + D_PHOTON);
-    HIPCHK(hipMemsetAsync(ctx->scalars.p + 2, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    TraceParams tp{};
+    fill_photon_params(ctx, tp, per_round, dep_cap, seed, replica, scratch_counters.p);
+    HIPCHK(hipMemsetAsync(ctx->scalars.p + SC_DEP, 0, sizeof(unsigned long long), ctx->stream));
     if (int rc = launch_fill(ctx, ctx->dcount.p, M + 1, 0)) { scratch_counters.release(); return rc; }
-    hipLaunchKernelGGL(k_photon_trace, dim3(ctx->num_cu * 4), dim3(256), (size_t)ctx->blob_bytes, ctx->stream, ctx->scene_params(), pp);
+    DevCounters* saved = ctx->counters.p;
+    ctx->counters.p = scratch_counters.p;   // run_rounds polls the overflow bits of the counters in use
+    const int rrc = run_rounds(ctx, MODE_PHOTON, tp, photon_begin, count, nullptr);
+    ctx->counters.p = saved;
     unsigned long long nd = 0;
-    hipError_t e = hipMemcpyAsync(&nd, ctx->scalars.p + 3, sizeof(nd), hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipMemcpyAsync(&nd, ctx->scalars.p + SC_DEP, sizeof(nd), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     scratch_counters.release();
+    if (rrc != SPPM_OK) return rrc;
     if (e != hipSuccess) return fail(ctx, SPPM_E_DEVICE, hipGetErrorString(e));
     *n = nd;
     const uint64_t m = std::min<uint64_t>(nd, cap);
