@@ -73,10 +73,14 @@ __device__ __forceinline__ uint32_t cell_coord(double p, double inv_cs) {
 __device__ __forceinline__ uint64_t cell_key(d3 p, double inv_cs) {
     return ((uint64_t)cell_coord(p.x, inv_cs) << 42) | ((uint64_t)cell_coord(p.y, inv_cs) << 21) | (uint64_t)cell_coord(p.z, inv_cs);
 }
+// Bucket of a cell: cells are grouped in 4 x 4 x 4 blocks; the block is hashed, the position inside the
+// block is the low 6 bits.  The 64 cells of a block are therefore 64 consecutive buckets, so after the
+// counting sort spatial neighbours are mostly memory neighbours (what the gather's L2 reuse rests on).
 __device__ __forceinline__ uint32_t key_bucket(uint64_t key, uint32_t mask) {
     uint32_t ix = (uint32_t)(key >> 42) & 0x1fffffu, iy = (uint32_t)(key >> 21) & 0x1fffffu, iz = (uint32_t)key & 0x1fffffu;
-    uint32_t h = (ix * 73856093u) ^ (iy * 19349663u) ^ (iz * 83492791u);
-    return fmix3(h) & mask;
+    uint32_t h = ((ix >> 2) * 73856093u) ^ ((iy >> 2) * 19349663u) ^ ((iz >> 2) * 83492791u);
+    uint32_t local = ((ix & 3u) << 4) | ((iy & 3u) << 2) | (iz & 3u);
+    return ((fmix3(h) << 6) | local) & mask;
 }
 
 // ------------------------------------------------------------------ LDS scene staging
@@ -134,6 +138,9 @@ __device__ __forceinline__ unsigned long long wave_alloc_n(uint32_t n, unsigned 
 }
 
 enum { MODE_EYE = 0, MODE_PHOTON = 1 };
+#define TRACE_WORK_CHUNK 128u     // work items a wave claims per atomic on the work counter
+#define TRACE_SLOT_CHUNK 256u     // deposit slots a wave claims per atomic on the deposit counter
+#define DEP_HOLE 0x00ffffffu      // DepB::bucket of a claimed but unused slot (buckets are < 2^22)
 
 struct TraceParams {
     // work items: [0, n_resume) = park records of the previous round, then fresh_count fresh
@@ -154,6 +161,7 @@ struct TraceParams {
     const DevLight* lights; int n_lights; uint32_t per_round;
     PosKey* depA; DepB* depB; unsigned long long* n_dep; unsigned long long dep_cap;
     uint32_t* dcount; GridParams grid;
+    unsigned long long* wave_chunks;          // per wave slot {next, end} of its open deposit-slot chunk
 };
 
 // One kernel for both passes, on persistent wavefronts: a lane that finishes (or parks) its
@@ -178,17 +186,33 @@ __global__ void __launch_bounds__(256, COOP ? 2 : 3) k_trace(SceneParams sp, Tra
     Near nr;
     near_init(nr);
     uint32_t ncalls = 0, nseg = 0, ndep = 0, nphot = 0;
+    // Work items and deposit slots are claimed from the global counters a chunk at a time (all waves
+    // hammering one address with a returned atomic per loop iteration serialises the whole grid).
+    unsigned long long work_next = 0, work_end = 0;     // this wave's claimed work items, wave-uniform
+    unsigned long long slot_next = 0, slot_end = 0;     // this wave's claimed deposit slots, wave-uniform
+    const uint32_t wave_slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (MODE == MODE_PHOTON) {
+        slot_next = tp.wave_chunks[2 * wave_slot];
+        slot_end = tp.wave_chunks[2 * wave_slot + 1];
+    }
     for (;;) {
         // ---- refill idle lanes
         const uint64_t idle = __ballot(!active);
-        if (idle && !exhausted) {
-            const unsigned long long n = (unsigned long long)__popcll(idle);
+        if (idle && work_next >= work_end && !exhausted) {
             unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(tp.next, n);
+            if (lane == 0) base = atomicAdd(tp.next, (unsigned long long)TRACE_WORK_CHUNK);
             base = bcast_u64(base, 0);
-            const unsigned long long my = base + (unsigned long long)__popcll(idle & lanemask_lt());
-            if (base + n >= total) exhausted = true;
-            if (!active && my < total) {
+            work_next = base < total ? base : total;
+            work_end = base + TRACE_WORK_CHUNK < total ? base + TRACE_WORK_CHUNK : total;
+            if (base + TRACE_WORK_CHUNK >= total) exhausted = true;
+        }
+        if (idle && work_next < work_end) {
+            const unsigned long long avail = work_end - work_next;
+            const unsigned long long rank = (unsigned long long)__popcll(idle & lanemask_lt());
+            const unsigned long long my = work_next + rank;
+            const unsigned long long n = (unsigned long long)__popcll(idle);
+            work_next += n < avail ? n : avail;
+            if (!active && rank < avail) {
                 active = true;
                 pending = false;
                 if (my < tp.n_resume) {
@@ -230,7 +254,10 @@ __global__ void __launch_bounds__(256, COOP ? 2 : 3) k_trace(SceneParams sp, Tra
                 }
             }
         }
-        if (!__any(active)) break;
+        if (!__any(active)) {
+            if (exhausted && work_next >= work_end) break;
+            continue;   // the chunk ran dry mid-refill: claim the next one
+        }
 
         // ---- Scene::NearCollide for lanes that carry an untraced ray
         const bool tracing = active && !pending;
@@ -394,15 +421,35 @@ __global__ void __launch_bounds__(256, COOP ? 2 : 3) k_trace(SceneParams sp, Tra
                 o = hit.pos; d = nd;
                 if (dep > SPPM_MAX_DEP) active = false;                                   // Raytracer.h:126-133
             }
-            const unsigned long long slot = wave_alloc(dp, tp.n_dep);
-            if (dp) {
-                ndep++;
-                if (slot < tp.dep_cap) {
-                    tp.depA[slot] = da; tp.depB[slot] = db;
-                    atomicAdd(&tp.dcount[db.bucket & 0xffffffu], 1u);
-                } else atomicOr(&tp.counters->overflow, 4u);
+            const uint64_t dm = __ballot(dp);
+            if (dm) {
+                const unsigned long long need = (unsigned long long)__popcll(dm);
+                const unsigned long long left = slot_end - slot_next;
+                const unsigned long long rank = (unsigned long long)__popcll(dm & lanemask_lt());
+                unsigned long long slot = slot_next + rank;
+                if (need > left) {   // the chunk runs out inside this wave-step: the first `left` lanes finish it, the rest open a new one
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(tp.n_dep, (unsigned long long)TRACE_SLOT_CHUNK);
+                    base = bcast_u64(base, 0);
+                    if (rank >= left) slot = base + (rank - left);
+                    slot_next = base + (need - left);
+                    slot_end = base + TRACE_SLOT_CHUNK;
+                } else {
+                    slot_next += need;
+                }
+                if (dp) {
+                    ndep++;
+                    if (slot < tp.dep_cap) {
+                        tp.depA[slot] = da; tp.depB[slot] = db;
+                        atomicAdd(&tp.dcount[db.bucket & 0xffffffu], 1u);
+                    } else atomicOr(&tp.counters->overflow, 4u);
+                }
             }
         }
+    }
+    if (MODE == MODE_PHOTON && lane == 0) {   // the open chunk stays with this wave slot for the next launch of the batch
+        tp.wave_chunks[2 * wave_slot] = slot_next;
+        tp.wave_chunks[2 * wave_slot + 1] = slot_end;
     }
     flush_counter(&tp.counters->newton_calls, ncalls);
     if (MODE == MODE_EYE) {
@@ -521,10 +568,21 @@ __global__ void k_dep_scatter(const PosKey* depA, const DepB* depB, const unsign
          i += (unsigned long long)gridDim.x * blockDim.x) {
         DepB b = depB[i];
         const uint32_t bk = b.bucket & 0xffffffu;
+        if (bk == DEP_HOLE) continue;
         uint32_t s = start[bk] + atomicAdd(&cursor[bk], 1u);
         sA[s] = depA[i];
         sB[s] = b;
     }
+}
+
+// Marks the unused tail of every wave slot's open chunk as holes (run once per batch, after the
+// last trace launch, before the deposits are sorted).
+__global__ void k_close_chunks(const unsigned long long* __restrict__ wave_chunks, uint32_t n_slots, DepB* depB, unsigned long long cap) {
+    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= n_slots) return;
+    const unsigned long long a = wave_chunks[2 * w], b = wave_chunks[2 * w + 1];
+    for (unsigned long long h = a + lane_id(); h < b; h += 64)
+        if (h < cap) depB[h].bucket = DEP_HOLE;
 }
 
 // ------------------------------------------------------------------ gather
@@ -725,6 +783,7 @@ struct sppm_ctx {
     // photon pass
     DevBuf<PosKey> depA, sdepA; DevBuf<DepB> depB, sdepB;
     DevBuf<uint32_t> dcount, dstart, scan_partial;
+    DevBuf<unsigned long long> wave_chunks;   // {next, end} of the open deposit-slot chunk of every trace wave slot
     DevBuf<unsigned long long> scalars;   // [0] n_hits, [1] n_tasks_out, [2] next photon, [3] n_dep
     DevBuf<DevCounters> counters;
     DevBuf<float> pic;
@@ -817,6 +876,7 @@ void sppm_destroy(sppm_ctx* ctx) {
     ctx->bucket_of.release(); ctx->hcount.release(); ctx->hstart.release(); ctx->cursor.release();
     ctx->hp_pos.release(); ctx->hp_nr.release(); ctx->hp_wgt.release(); ctx->hp_tao.release(); ctx->hp_meta.release();
     ctx->depA.release(); ctx->sdepA.release(); ctx->depB.release(); ctx->sdepB.release();
+    ctx->wave_chunks.release();
     ctx->dcount.release(); ctx->dstart.release(); ctx->scan_partial.release(); ctx->scalars.release(); ctx->counters.release(); ctx->pic.release();
     if (ctx->ev[0]) (void)hipEventDestroy(ctx->ev[0]);
     if (ctx->ev[1]) (void)hipEventDestroy(ctx->ev[1]);
@@ -953,6 +1013,30 @@ static int launch_scan(sppm_ctx* ctx, const uint32_t* cnt, uint32_t* start, uint
 // scalars: device-side counters shared by the passes
 enum { SC_HITS = 0, SC_NEXT = 2, SC_DEP = 3, SC_PARK0 = 4, SC_TASK0 = 5, SC_PARK1 = 6, SC_TASK1 = 7 };
 
+static int trace_max_blocks(const sppm_ctx* ctx) { return ctx->num_cu * 4; }
+// deposit slots that can be left unused in open chunks (one chunk per wave slot of the largest trace grid)
+static uint64_t dep_slack(const sppm_ctx* ctx) { return (uint64_t)trace_max_blocks(ctx) * 4u * TRACE_SLOT_CHUNK; }
+
+// Resets the deposit queue of a batch: slot counter, per-wave open chunks, bucket histogram.
+static int begin_deposit_batch(sppm_ctx* ctx) {
+    const uint32_t M = ctx->grid.mask + 1;
+    const size_t n_slots = (size_t)trace_max_blocks(ctx) * 4;
+    HIPCHK(ctx->wave_chunks.reserve(2 * n_slots));
+    HIPCHK(hipMemsetAsync(ctx->scalars.p + SC_DEP, 0, sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->wave_chunks.p, 0, 2 * n_slots * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, ctx->stream, ctx->dcount.p, (size_t)M + 1, 0u);
+    HIPCHK(hipGetLastError());
+    return SPPM_OK;
+}
+// Turns the unused tails of the open chunks into holes once the batch's trace launches are done.
+static int end_deposit_batch(sppm_ctx* ctx, uint64_t dep_cap) {
+    const uint32_t n_slots = (uint32_t)trace_max_blocks(ctx) * 4u;
+    hipLaunchKernelGGL(k_close_chunks, dim3((n_slots + 3) / 4), dim3(256), 0, ctx->stream, ctx->wave_chunks.p, n_slots, ctx->depB.p,
+                       (unsigned long long)dep_cap);
+    HIPCHK(hipGetLastError());
+    return SPPM_OK;
+}
+
 template <int MODE>
 static void launch_trace(sppm_ctx* ctx, bool coop, int blocks, const SceneParams& sp, const TraceParams& tp) {
     if (coop) hipLaunchKernelGGL((k_trace<MODE, true>), dim3(blocks), dim3(256), (size_t)ctx->blob_bytes, ctx->stream, sp, tp);
@@ -976,7 +1060,7 @@ static int run_rounds(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fi
     tp.park_cap = park_cap; tp.task_cap = task_cap;
     tp.resume = nullptr; tp.n_resume = 0; tp.tasks_in = nullptr; tp.res_in = nullptr;
     tp.fresh_first = fresh_first; tp.fresh_count = fresh_count;
-    const int max_blocks = ctx->num_cu * 4;
+    const int max_blocks = trace_max_blocks(ctx);
     auto blocks_for = [&](uint64_t items) { return (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)max_blocks, (items + 255) / 256)); };
     int cur = 0;
     tp.park_out = ctx->park[0].p; tp.n_park = sc + SC_PARK0; tp.tasks_out = ctx->ntask[0].p; tp.n_tasks = sc + SC_TASK0;
@@ -1087,6 +1171,7 @@ static void fill_photon_params(sppm_ctx* ctx, TraceParams& tp, uint32_t per_roun
     tp.lights = ctx->lights.p; tp.n_lights = ctx->n_lights; tp.per_round = per_round;
     tp.depA = ctx->depA.p; tp.depB = ctx->depB.p; tp.n_dep = ctx->scalars.p + SC_DEP; tp.dep_cap = dep_cap;
     tp.dcount = ctx->dcount.p; tp.grid = ctx->grid; tp.counters = counters;
+    tp.wave_chunks = ctx->wave_chunks.p;
     tp.rng = host_rng_base(seed, replica * 4u + D_PHOTON);
 }
 
@@ -1103,20 +1188,21 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
     ctx->last_rounds = rounds; ctx->last_per_round = per_round;
     const uint32_t M = ctx->grid.mask + 1;
     const uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(ctx->batch, end > photon_begin ? end - photon_begin : 1));
-    const uint64_t dep_cap = batch * (SPPM_MAX_DEP + 1);
+    const uint64_t dep_cap = batch * (SPPM_MAX_DEP + 1) + dep_slack(ctx);
     HIPCHK(ctx->depA.reserve(dep_cap)); HIPCHK(ctx->depB.reserve(dep_cap));
     HIPCHK(ctx->sdepA.reserve(dep_cap)); HIPCHK(ctx->sdepB.reserve(dep_cap));
+    HIPCHK(ctx->wave_chunks.reserve(2 * (size_t)trace_max_blocks(ctx) * 4));
     TraceParams tp{};
     fill_photon_params(ctx, tp, per_round, dep_cap, seed, replica, ctx->counters.p);
     ctx->tm.photon_trace_ms = ctx->tm.deposit_sort_ms = ctx->tm.gather_ms = 0;
     ctx->tm.gather_launches = 0;
     for (uint64_t first = photon_begin; first < end; first += batch) {
         const uint64_t count = std::min(batch, end - first);
-        HIPCHK(hipMemsetAsync(ctx->scalars.p + SC_DEP, 0, sizeof(unsigned long long), ctx->stream));
-        if (int rc = launch_fill(ctx, ctx->dcount.p, M + 1, 0)) return rc;
+        if (int rc = begin_deposit_batch(ctx)) return rc;
         if (int rc = launch_fill(ctx, ctx->cursor.p, M + 1, 0)) return rc;
         tic(ctx);
         if (int rc = run_rounds(ctx, MODE_PHOTON, tp, first, count, nullptr)) return rc;
+        if (int rc = end_deposit_batch(ctx, dep_cap)) return rc;
         ctx->tm.photon_trace_ms += toc(ctx);
         tic(ctx);
         if (int rc = launch_scan(ctx, ctx->dcount.p, ctx->dstart.p, M)) return rc;
@@ -1251,42 +1337,48 @@ int sppm_debug_photon_deposits(sppm_ctx* ctx, uint64_t rounds, uint32_t per_roun
     const uint64_t count = std::min(photon_count, total - photon_begin);
     if (count > (1u << 22)) return fail(ctx, SPPM_E_INVALID, "at most 2^22 photons per debug call");
     HIPCHK(hipSetDevice(ctx->device));
-    const uint32_t M = ctx->grid.mask + 1;
-    const uint64_t dep_cap = count * (SPPM_MAX_DEP + 1);
+    const uint64_t dep_cap = count * (SPPM_MAX_DEP + 1) + dep_slack(ctx);
     HIPCHK(ctx->depA.reserve(dep_cap)); HIPCHK(ctx->depB.reserve(dep_cap));
     HIPCHK(ctx->sdepA.reserve(dep_cap)); HIPCHK(ctx->sdepB.reserve(dep_cap));
+    HIPCHK(ctx->wave_chunks.reserve(2 * (size_t)trace_max_blocks(ctx) * 4));
     DevBuf<DevCounters> scratch_counters;   // keep the pass counters untouched
     HIPCHK(scratch_counters.reserve(1));
     HIPCHK(hipMemsetAsync(scratch_counters.p, 0, sizeof(DevCounters), ctx->stream));
     TraceParams tp{};
     fill_photon_params(ctx, tp, per_round, dep_cap, seed, replica, scratch_counters.p);
-    HIPCHK(hipMemsetAsync(ctx->scalars.p + SC_DEP, 0, sizeof(unsigned long long), ctx->stream));
-    if (int rc = launch_fill(ctx, ctx->dcount.p, M + 1, 0)) { scratch_counters.release(); return rc; }
+    if (int rc = begin_deposit_batch(ctx)) { scratch_counters.release(); return rc; }
     DevCounters* saved = ctx->counters.p;
     ctx->counters.p = scratch_counters.p;   // run_rounds polls the overflow bits of the counters in use
-    const int rrc = run_rounds(ctx, MODE_PHOTON, tp, photon_begin, count, nullptr);
+    int rrc = run_rounds(ctx, MODE_PHOTON, tp, photon_begin, count, nullptr);
     ctx->counters.p = saved;
+    if (rrc == SPPM_OK) rrc = end_deposit_batch(ctx, dep_cap);
     unsigned long long nd = 0;
     hipError_t e = hipMemcpyAsync(&nd, ctx->scalars.p + SC_DEP, sizeof(nd), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     scratch_counters.release();
     if (rrc != SPPM_OK) return rrc;
     if (e != hipSuccess) return fail(ctx, SPPM_E_DEVICE, hipGetErrorString(e));
-    *n = nd;
-    const uint64_t m = std::min<uint64_t>(nd, cap);
-    if (m) {
-        std::vector<PosKey> a(m); std::vector<DepB> b(m);
-        HIPCHK(hipMemcpy(a.data(), ctx->depA.p, m * sizeof(PosKey), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(b.data(), ctx->depB.p, m * sizeof(DepB), hipMemcpyDeviceToHost));
-        for (uint64_t i = 0; i < m; i++) {
-            double* o = out + 11 * i;
-            o[0] = (double)b[i].photon; o[1] = (double)(b[i].bucket >> 24);
-            o[2] = a[i].x; o[3] = a[i].y; o[4] = a[i].z;
-            o[5] = b[i].nx; o[6] = b[i].ny; o[7] = b[i].nz;
-            o[8] = b[i].fr; o[9] = b[i].fg; o[10] = b[i].fb;
+    // nd counts claimed slots; unused ones are holes
+    const uint64_t claimed = std::min<uint64_t>(nd, dep_cap);
+    uint64_t real = 0;
+    if (claimed) {
+        std::vector<PosKey> a(claimed); std::vector<DepB> b(claimed);
+        HIPCHK(hipMemcpy(a.data(), ctx->depA.p, claimed * sizeof(PosKey), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(b.data(), ctx->depB.p, claimed * sizeof(DepB), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < claimed; i++) {
+            if ((b[i].bucket & 0xffffffu) == DEP_HOLE) continue;
+            if (real < cap) {
+                double* o = out + 11 * real;
+                o[0] = (double)b[i].photon; o[1] = (double)(b[i].bucket >> 24);
+                o[2] = a[i].x; o[3] = a[i].y; o[4] = a[i].z;
+                o[5] = b[i].nx; o[6] = b[i].ny; o[7] = b[i].nz;
+                o[8] = b[i].fr; o[9] = b[i].fg; o[10] = b[i].fb;
+            }
+            real++;
         }
     }
-    return nd <= cap ? SPPM_OK : SPPM_E_CAPACITY;
+    *n = real;
+    return real <= cap ? SPPM_OK : SPPM_E_CAPACITY;
 }
 
 int sppm_debug_newton(sppm_ctx* ctx, uint64_t n, const double* org, const double* dir, const int32_t* patch, uint64_t seed,
