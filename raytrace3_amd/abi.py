@@ -115,7 +115,9 @@ def bind(lib, symbols):
     return lib
 
 
-def load_library(path=LIB_PATH):
+def load_library(path=None):
+    # SPPM_LIB_PATH selects another build of the same library (kernel A/B experiments)
+    path = path or os.environ.get("SPPM_LIB_PATH") or LIB_PATH
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

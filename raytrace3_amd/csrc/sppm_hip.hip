@@ -586,75 +586,131 @@ __global__ void k_close_chunks(const unsigned long long* __restrict__ wave_chunk
 }
 
 // ------------------------------------------------------------------ gather
-// The radius search + HitPoint update of Raytracer.h:146-159, turned around: HitPoints own
-// the accumulation.  One wave owns a tile of 64 grid-sorted HitPoints; for each of them the
-// lanes stream the deposits of the 27 neighbouring cells (contiguous after the sort) and apply
+// The radius search + HitPoint update of Raytracer.h:146-159, turned around: HitPoints own the
+// accumulation, and the HitPoints of one grid cell share one sweep over the deposits around them.
 //   dist^2 < searchR2  &&  hp.n . N > 1e-3  &&  dist^2 <= hp.R2   ->   newN++, tao += wgt * flux * PI_INV
-// per lane, then the wave reduces and the owner lane adds the sum to its HitPoint.
+// A wave owns a tile of 64 grid-sorted HitPoints and walks the distinct cells in it.  For a cell,
+// lanes 0..26 look up the deposit ranges of the 27 neighbour cells; the ranges are cut into rows
+// of 64 deposits (contiguous after the sort: one coalesced 32 B + 32 B load per lane) and
+// GATHER_ROWS rows at a time are held in registers while every HitPoint of the cell is broadcast
+// across the wave and tested against them.  Per (HitPoint, pass) the accepted flux is summed over
+// the lanes with DPP adds, the counts with ballots; the owner lane keeps the running sums and
+// writes its HitPoint once: no atomics on HitPoints, and a deposit is fetched once per cell
+// instead of once per HitPoint.
+#ifndef GATHER_ROWS
+#define GATHER_ROWS 4
+#endif
+
+// Sum over the 64 lanes, returned wave-uniform.
+__device__ __forceinline__ float wave_total_f(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));   // row_mirror: every lane = its row's sum
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1, 3
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2, 3
+    return bcast_f(v, 63);
+}
+
 __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
                                                 const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
                                                 const uint32_t* __restrict__ dstart, const PosKey* __restrict__ dA,
                                                 const DepB* __restrict__ dB, GridParams g, DevCounters* counters) {
     const int lane = lane_id();
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t base = wave * 64u;
+    // Workgroups are dealt round-robin to the 8 XCDs; give each XCD one contiguous eighth of the tiles
+    // so that tiles in flight on an XCD are neighbours in bucket order and share their L2.
+    const uint32_t per_xcd = gridDim.x >> 3;
+    const uint32_t block = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const uint32_t base = (block * 4u + (threadIdx.x >> 6)) * 64u;
     if (base >= n_hp) return;
     const uint32_t mine = base + lane;
     const bool valid = mine < n_hp;
-    PosKey mp = hp_pos[valid ? mine : base];
-    float4 mnr = hp_nr[valid ? mine : base];
-    float4 mw = hp_wgt[valid ? mine : base];
+    const PosKey mp = hp_pos[valid ? mine : base];
+    const float4 mnr = hp_nr[valid ? mine : base];
+    const float4 mw = hp_wgt[valid ? mine : base];
     float tr = 0, tg = 0, tb = 0;
-    uint32_t tn = 0, cand = 0, acc_n = 0;
-    const int cnt = (int)min(64u, n_hp - base);
-    uint64_t prev_key = ~0ull;
-    uint32_t nb_s = 0, nb_e = 0;
-    uint64_t nb_key = 0;
-    for (int j = 0; j < cnt; j++) {
-        const double hx = bcast_d(mp.x, j), hy = bcast_d(mp.y, j), hz = bcast_d(mp.z, j);
-        const uint64_t hkey = bcast_u64(mp.key, j);
-        const float nx = bcast_f(mnr.x, j), ny = bcast_f(mnr.y, j), nz = bcast_f(mnr.z, j), R2 = bcast_f(mnr.w, j);
-        const float wr = bcast_f(mw.x, j), wg = bcast_f(mw.y, j), wb = bcast_f(mw.z, j);
-        if (hkey != prev_key) {   // lanes 0..26 look up the deposit ranges of the 27 neighbour cells
-            prev_key = hkey;
-            nb_s = nb_e = 0; nb_key = 0;
-            if (lane < 27) {
-                int dx = lane % 3 - 1, dy = (lane / 3) % 3 - 1, dz = lane / 9 - 1;
-                nb_key = hkey + ((uint64_t)(int64_t)dx << 42) + ((uint64_t)(int64_t)dy << 21) + (uint64_t)(int64_t)dz;
-                uint32_t b = key_bucket(nb_key, g.mask);
-                nb_s = dstart[b]; nb_e = dstart[b + 1];
-            }
+    uint32_t tn = 0;
+    uint32_t cand = 0, acc_n = 0;   // wave-uniform tallies
+    uint64_t todo = __ballot(valid);
+    while (todo) {
+        const int lead = __ffsll((unsigned long long)todo) - 1;
+        const uint64_t key = bcast_u64(mp.key, lead);
+        const uint64_t grp = __ballot(valid && mp.key == key);   // the HitPoints of this cell in the tile
+        todo &= ~grp;
+        uint32_t nb_s = 0, nb_len = 0;
+        uint64_t nb_key = 0;
+        if (lane < 27) {
+            const int dx = lane % 3 - 1, dy = (lane / 3) % 3 - 1, dz = lane / 9 - 1;
+            nb_key = key + ((uint64_t)(int64_t)dx << 42) + ((uint64_t)(int64_t)dy << 21) + (uint64_t)(int64_t)dz;
+            const uint32_t b = key_bucket(nb_key, g.mask);
+            nb_s = dstart[b];
+            nb_len = dstart[b + 1] - nb_s;
         }
-        float pr = 0, pg = 0, pb = 0;
-        uint32_t pn = 0;
-        uint64_t nonempty = __ballot(nb_e > nb_s);
-        while (nonempty) {
-            int k = __ffsll((unsigned long long)nonempty) - 1;
-            nonempty &= nonempty - 1;
-            const uint32_t s = bcast_u(nb_s, k), e = bcast_u(nb_e, k);
-            const uint64_t key = bcast_u64(nb_key, k);
-            for (uint32_t i = s + lane; i < e; i += 64) {
-                const PosKey a = dA[i];
-                if (a.key != key) continue;   // another cell hashed into this bucket
-                const double vx = hx - a.x, vy = hy - a.y, vz = hz - a.z;
-                const double d2 = vx * vx + vy * vy + vz * vz;
-                if (d2 < SPPM_INIT_R2) {      // flann radiusSearch(radius = searchR2): strict '<' on the squared distance
-                    cand++;
-                    const DepB b = dB[i];
-                    if ((nx * b.nx + ny * b.ny + nz * b.nz > 1e-3f) && (d2 <= (double)R2)) {
-                        pn++;
-                        pr += (wr * b.fr) * (float)SPPM_PI_INV;
-                        pg += (wg * b.fg) * (float)SPPM_PI_INV;
-                        pb += (wb * b.fb) * (float)SPPM_PI_INV;
+        uint64_t cells = __ballot(nb_len > 0);
+        uint32_t cs = 0, ce = 0;        // rest of the current neighbour cell's deposit range, wave-uniform
+        uint64_t ckey = 0;
+        while (cs < ce || cells) {
+            double ax[GATHER_ROWS], ay[GATHER_ROWS], az[GATHER_ROWS];
+            float bnx[GATHER_ROWS], bny[GATHER_ROWS], bnz[GATHER_ROWS], bfr[GATHER_ROWS], bfg[GATHER_ROWS], bfb[GATHER_ROWS];
+            int rows = 0;
+#pragma unroll
+            for (int r = 0; r < GATHER_ROWS; r++) {
+                ax[r] = ay[r] = az[r] = 1e30;
+                bnx[r] = bny[r] = bnz[r] = bfr[r] = bfg[r] = bfb[r] = 0.0f;
+                if (cs >= ce && cells) {
+                    const int k = __ffsll((unsigned long long)cells) - 1;
+                    cells &= cells - 1;
+                    cs = bcast_u(nb_s, k);
+                    ce = cs + bcast_u(nb_len, k);
+                    ckey = bcast_u64(nb_key, k);
+                }
+                if (cs < ce) {
+                    rows = r + 1;
+                    const uint32_t i = cs + lane;
+                    if (i < ce) {
+                        const PosKey a = dA[i];
+                        if (a.key == ckey) {   // else: another cell hashed into this bucket
+                            const DepB b = dB[i];
+                            ax[r] = a.x; ay[r] = a.y; az[r] = a.z;
+                            bnx[r] = b.nx; bny[r] = b.ny; bnz[r] = b.nz;
+                            bfr[r] = b.fr * (float)SPPM_PI_INV; bfg[r] = b.fg * (float)SPPM_PI_INV; bfb[r] = b.fb * (float)SPPM_PI_INV;
+                        }
                     }
+                    cs += 64;
                 }
             }
-        }
-        if (__any(pn != 0)) {
-            pr = wave_sum_f(pr); pg = wave_sum_f(pg); pb = wave_sum_f(pb);
-            pn = wave_sum_u(pn);
-            if (lane == j) { tr += pr; tg += pg; tb += pb; tn += pn; }
-            if (lane == 0) acc_n += pn;
+            uint64_t gm = grp;
+            while (gm) {
+                const int j = __ffsll((unsigned long long)gm) - 1;
+                gm &= gm - 1;
+                const double hx = bcast_d(mp.x, j), hy = bcast_d(mp.y, j), hz = bcast_d(mp.z, j);
+                const float nx = bcast_f(mnr.x, j), ny = bcast_f(mnr.y, j), nz = bcast_f(mnr.z, j);
+                const double R2 = (double)bcast_f(mnr.w, j);
+                const float wr = bcast_f(mw.x, j), wg = bcast_f(mw.y, j), wb = bcast_f(mw.z, j);
+                float pr = 0, pg = 0, pb = 0;
+                uint32_t pn = 0;
+#pragma unroll
+                for (int r = 0; r < GATHER_ROWS; r++) {
+                    if (r < rows) {
+                        const double vx = hx - ax[r], vy = hy - ay[r], vz = hz - az[r];
+                        const double d2 = vx * vx + vy * vy + vz * vz;
+                        const bool c = d2 < SPPM_INIT_R2;      // flann radiusSearch(radius = searchR2): strict '<' on the squared distance
+                        const bool ok = c && (nx * bnx[r] + ny * bny[r] + nz * bnz[r] > 1e-3f) && (d2 <= R2);
+                        cand += (uint32_t)__popcll(__ballot(c));
+                        pn += (uint32_t)__popcll(__ballot(ok));
+                        if (ok) {
+                            pr = fmaf(wr, bfr[r], pr);
+                            pg = fmaf(wg, bfg[r], pg);
+                            pb = fmaf(wb, bfb[r], pb);
+                        }
+                    }
+                }
+                if (pn) {
+                    pr = wave_total_f(pr); pg = wave_total_f(pg); pb = wave_total_f(pb);
+                    if (lane == j) { tr += pr; tg += pg; tb += pb; tn += pn; }
+                    acc_n += pn;
+                }
+            }
         }
     }
     if (valid && tn) {
@@ -663,8 +719,10 @@ __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_po
         t.w = __int_as_float(__float_as_int(t.w) + (int)tn);
         hp_tao[mine] = t;
     }
-    flush_counter(&counters->candidates, cand);
-    flush_counter(&counters->accepted, acc_n);
+    if (lane == 0) {
+        if (cand) atomicAdd(&counters->candidates, (unsigned long long)cand);
+        if (acc_n) atomicAdd(&counters->accepted, (unsigned long long)acc_n);
+    }
 }
 
 // ------------------------------------------------------------------ resolve (Raytracer.h:281-293)
@@ -1213,7 +1271,7 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
         if (ctx->n_hp > 0) {
             tic(ctx);
             const int waves = (int)((ctx->n_hp + 63) / 64);
-            const int blocks = (waves + 3) / 4;
+            const int blocks = (((waves + 3) / 4 + 7) / 8) * 8;   // a multiple of 8: the kernel deals blocks to XCDs
             hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->hp_tao.p,
                                (uint32_t)ctx->n_hp, ctx->dstart.p, ctx->sdepA.p, ctx->sdepB.p, ctx->grid, ctx->counters.p);
             HIPCHK(hipGetLastError());
