@@ -833,6 +833,8 @@ struct sppm_ctx {
     DevBuf<ParkRec> park[2]; DevBuf<NewtonTask> ntask[2]; DevBuf<float4> nres;
     uint64_t coop_threshold = 4096;   // rounds with fewer parked rays finish inside the trace kernel
     bool force_coop = false;
+    bool photon_coop = true;
+    int newton_blocks_per_cu = 8;
     bool verbose = false;
     DevBuf<uint32_t> bucket_of, hcount, hstart, cursor;
     DevBuf<PosKey> hp_pos; DevBuf<float4> hp_nr, hp_wgt, hp_tao; DevBuf<HpMeta> hp_meta;
@@ -915,6 +917,8 @@ int sppm_create(sppm_ctx** out, int device_id) {
     }
     if (const char* b = getenv("SPPM_COOP_THRESHOLD")) ctx->coop_threshold = (uint64_t)std::max(0ll, atoll(b));
     if (const char* b = getenv("SPPM_FORCE_COOP")) ctx->force_coop = atoi(b) != 0;
+    if (const char* b = getenv("SPPM_PHOTON_COOP")) ctx->photon_coop = atoi(b) != 0;
+    if (const char* b = getenv("SPPM_NEWTON_BPC")) ctx->newton_blocks_per_cu = std::max(1, atoi(b));
     if (const char* b = getenv("SPPM_VERBOSE")) ctx->verbose = atoi(b) != 0;
     if (ctx->scalars.reserve(8) != hipSuccess || ctx->counters.reserve(1) != hipSuccess) {
         delete ctx;
@@ -1122,7 +1126,10 @@ static int run_rounds(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fi
     auto blocks_for = [&](uint64_t items) { return (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)max_blocks, (items + 255) / 256)); };
     int cur = 0;
     tp.park_out = ctx->park[0].p; tp.n_park = sc + SC_PARK0; tp.tasks_out = ctx->ntask[0].p; tp.n_tasks = sc + SC_TASK0;
-    bool coop = ctx->force_coop;
+    // Eye rays that meet a Bezier object are neighbours in the image, so whole waves would stall in the
+    // in-wave solve while others idle: they are parked and solved by k_newton.  Photons meet it at random,
+    // a few lanes per wave: solving in place costs less than the extra launches of a park round.
+    bool coop = ctx->force_coop || (mode == MODE_PHOTON && ctx->photon_coop);
     if (mode == MODE_EYE) launch_trace<MODE_EYE>(ctx, coop, blocks_for(fresh_count), sp, tp);
     else launch_trace<MODE_PHOTON>(ctx, coop, blocks_for(fresh_count), sp, tp);
     HIPCHK(hipGetLastError());
@@ -1139,7 +1146,7 @@ static int run_rounds(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fi
         if (ctx->verbose) fprintf(stderr, "[sppm] mode %d round %d: parked %llu rays, %llu newton tasks\n", mode, round, n_park, n_tasks);
         if (n_park == 0) return SPPM_OK;
         if (n_tasks > 0) {
-            const int nb = (int)std::min<uint64_t>((n_tasks + 3) / 4, (uint64_t)ctx->num_cu * 32);
+            const int nb = (int)std::min<uint64_t>((n_tasks + 3) / 4, (uint64_t)ctx->num_cu * ctx->newton_blocks_per_cu);
             hipLaunchKernelGGL(k_newton, dim3(nb), dim3(256), 0, ctx->stream, ctx->park[cur].p, ctx->ntask[cur].p, (uint32_t)n_tasks,
                                (const float*)(ctx->blob.p + ctx->off_cp), ctx->nres.p, ctx->counters.p);
         }
@@ -1150,7 +1157,7 @@ static int run_rounds(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fi
         tp.fresh_first = 0; tp.fresh_count = 0;
         tp.park_out = ctx->park[nxt].p; tp.n_park = sc + (nxt ? SC_PARK1 : SC_PARK0);
         tp.tasks_out = ctx->ntask[nxt].p; tp.n_tasks = sc + (nxt ? SC_TASK1 : SC_TASK0);
-        coop = ctx->force_coop || n_park < ctx->coop_threshold;
+        coop = ctx->force_coop || (mode == MODE_PHOTON && ctx->photon_coop) || n_park < ctx->coop_threshold;
         if (mode == MODE_EYE) launch_trace<MODE_EYE>(ctx, coop, blocks_for(n_park), sp, tp);
         else launch_trace<MODE_PHOTON>(ctx, coop, blocks_for(n_park), sp, tp);
         HIPCHK(hipGetLastError());
