@@ -598,7 +598,7 @@ __global__ void k_close_chunks(const unsigned long long* __restrict__ wave_chunk
 // writes its HitPoint once: no atomics on HitPoints, and a deposit is fetched once per cell
 // instead of once per HitPoint.
 #ifndef GATHER_ROWS
-#define GATHER_ROWS 4
+#define GATHER_ROWS 6
 #endif
 
 // Sum over the 64 lanes, returned wave-uniform.
@@ -612,17 +612,12 @@ __device__ __forceinline__ float wave_total_f(float v) {
     return bcast_f(v, 63);
 }
 
-__global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
-                                                const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
-                                                const uint32_t* __restrict__ dstart, const PosKey* __restrict__ dA,
-                                                const DepB* __restrict__ dB, GridParams g, DevCounters* counters) {
+// One tile = 64 consecutive grid-sorted HitPoints, one per lane.
+__device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
+                                            const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, const uint32_t n_hp,
+                                            const uint32_t* __restrict__ dstart, const PosKey* __restrict__ dA,
+                                            const DepB* __restrict__ dB, const GridParams g, uint32_t& cand, uint32_t& acc_n) {
     const int lane = lane_id();
-    // Workgroups are dealt round-robin to the 8 XCDs; give each XCD one contiguous eighth of the tiles
-    // so that tiles in flight on an XCD are neighbours in bucket order and share their L2.
-    const uint32_t per_xcd = gridDim.x >> 3;
-    const uint32_t block = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    const uint32_t base = (block * 4u + (threadIdx.x >> 6)) * 64u;
-    if (base >= n_hp) return;
     const uint32_t mine = base + lane;
     const bool valid = mine < n_hp;
     const PosKey mp = hp_pos[valid ? mine : base];
@@ -630,7 +625,6 @@ __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_po
     const float4 mw = hp_wgt[valid ? mine : base];
     float tr = 0, tg = 0, tb = 0;
     uint32_t tn = 0;
-    uint32_t cand = 0, acc_n = 0;   // wave-uniform tallies
     uint64_t todo = __ballot(valid);
     while (todo) {
         const int lead = __ffsll((unsigned long long)todo) - 1;
@@ -646,10 +640,13 @@ __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_po
             nb_s = dstart[b];
             nb_len = dstart[b + 1] - nb_s;
         }
+        // The non-empty ranges, concatenated, form one flat list; a row is 64 consecutive entries of it
+        // (lane l of the row at flat offset F holds entry F + l), so rows are full except the last.
         uint64_t cells = __ballot(nb_len > 0);
-        uint32_t cs = 0, ce = 0;        // rest of the current neighbour cell's deposit range, wave-uniform
-        uint64_t ckey = 0;
-        while (cs < ce || cells) {
+        uint32_t F = 0;                     // flat offset of the next row
+        uint32_t cur_end = 0, cur_base = 0; // current range: flat end, (deposit index - flat index)
+        uint32_t cur_klo = 0, cur_khi = 0;  // its cell key
+        while (cells || F < cur_end) {
             double ax[GATHER_ROWS], ay[GATHER_ROWS], az[GATHER_ROWS];
             float bnx[GATHER_ROWS], bny[GATHER_ROWS], bnz[GATHER_ROWS], bfr[GATHER_ROWS], bfg[GATHER_ROWS], bfb[GATHER_ROWS];
             int rows = 0;
@@ -657,26 +654,31 @@ __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_po
             for (int r = 0; r < GATHER_ROWS; r++) {
                 ax[r] = ay[r] = az[r] = 1e30;
                 bnx[r] = bny[r] = bnz[r] = bfr[r] = bfg[r] = bfb[r] = 0.0f;
-                if (cs >= ce && cells) {
-                    const int k = __ffsll((unsigned long long)cells) - 1;
-                    cells &= cells - 1;
-                    cs = bcast_u(nb_s, k);
-                    ce = cs + bcast_u(nb_len, k);
-                    ckey = bcast_u64(nb_key, k);
-                }
-                if (cs < ce) {
+                if (cells || F < cur_end) {
                     rows = r + 1;
-                    const uint32_t i = cs + lane;
-                    if (i < ce) {
-                        const PosKey a = dA[i];
-                        if (a.key == ckey) {   // else: another cell hashed into this bucket
-                            const DepB b = dB[i];
+                    const uint32_t f = F + lane;
+                    uint32_t src = cur_base + f, klo = cur_klo, khi = cur_khi;
+                    bool in = f < cur_end;
+                    while (cur_end < F + 64 && cells) {   // ranges that begin inside this row
+                        const int k = __ffsll((unsigned long long)cells) - 1;
+                        cells &= cells - 1;
+                        const uint32_t start = cur_end;
+                        cur_base = bcast_u(nb_s, k) - start;
+                        cur_end = start + bcast_u(nb_len, k);
+                        cur_klo = bcast_u((uint32_t)nb_key, k);
+                        cur_khi = bcast_u((uint32_t)(nb_key >> 32), k);
+                        if (f >= start) { src = cur_base + f; klo = cur_klo; khi = cur_khi; in = f < cur_end; }
+                    }
+                    F += 64;
+                    if (in) {
+                        const PosKey a = dA[src];
+                        const DepB b = dB[src];     // fetched with the position, not after the key check: one memory latency per row
+                        if (a.key == (((uint64_t)khi << 32) | klo)) {   // else: another cell hashed into this bucket
                             ax[r] = a.x; ay[r] = a.y; az[r] = a.z;
                             bnx[r] = b.nx; bny[r] = b.ny; bnz[r] = b.nz;
                             bfr[r] = b.fr * (float)SPPM_PI_INV; bfg[r] = b.fg * (float)SPPM_PI_INV; bfb[r] = b.fb * (float)SPPM_PI_INV;
                         }
                     }
-                    cs += 64;
                 }
             }
             uint64_t gm = grp;
@@ -695,14 +697,13 @@ __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_po
                         const double vx = hx - ax[r], vy = hy - ay[r], vz = hz - az[r];
                         const double d2 = vx * vx + vy * vy + vz * vz;
                         const bool c = d2 < SPPM_INIT_R2;      // flann radiusSearch(radius = searchR2): strict '<' on the squared distance
-                        const bool ok = c && (nx * bnx[r] + ny * bny[r] + nz * bnz[r] > 1e-3f) && (d2 <= R2);
-                        cand += (uint32_t)__popcll(__ballot(c));
-                        pn += (uint32_t)__popcll(__ballot(ok));
-                        if (ok) {
-                            pr = fmaf(wr, bfr[r], pr);
-                            pg = fmaf(wg, bfg[r], pg);
-                            pb = fmaf(wb, bfb[r], pb);
-                        }
+                        const float dn = nx * bnx[r] + ny * bny[r] + nz * bnz[r];
+                        const bool ok = c & (dn > 1e-3f) & (d2 <= R2);
+                        cand += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(c));
+                        pn += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ok));
+                        pr = ok ? fmaf(wr, bfr[r], pr) : pr;
+                        pg = ok ? fmaf(wg, bfg[r], pg) : pg;
+                        pb = ok ? fmaf(wb, bfb[r], pb) : pb;
                     }
                 }
                 if (pn) {
@@ -719,7 +720,31 @@ __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_po
         t.w = __int_as_float(__float_as_int(t.w) + (int)tn);
         hp_tao[mine] = t;
     }
-    if (lane == 0) {
+}
+
+// Persistent waves; tiles are handed out by eight counters, one per eighth of the tile range.  A
+// workgroup starts on the eighth of its XCD (workgroups are dealt round-robin to the 8 XCDs), so the
+// tiles in flight on one XCD are neighbours in bucket order and share its L2, and moves on to the
+// other eighths when its own is drained (tile cost varies with the photon density around it).
+__global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
+                                                const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
+                                                const uint32_t* __restrict__ dstart, const PosKey* __restrict__ dA,
+                                                const DepB* __restrict__ dB, GridParams g, uint32_t* tile_ctr, DevCounters* counters) {
+    const uint32_t n_tiles = (n_hp + 63u) >> 6;
+    const uint32_t per = (n_tiles + 7u) >> 3;
+    uint32_t cand = 0, acc_n = 0;   // wave-uniform tallies
+    for (uint32_t s = 0; s < 8; s++) {
+        const uint32_t q = (blockIdx.x + s) & 7u;
+        const uint32_t q_end = min(n_tiles, (q + 1) * per);
+        for (;;) {
+            uint32_t t = 0;
+            if (lane_id() == 0) t = atomicAdd(&tile_ctr[q * 16], 1u);
+            t = bcast_u(t, 0) + q * per;
+            if (t >= q_end) break;
+            gather_tile(t * 64u, hp_pos, hp_nr, hp_wgt, hp_tao, n_hp, dstart, dA, dB, g, cand, acc_n);
+        }
+    }
+    if (lane_id() == 0) {
         if (cand) atomicAdd(&counters->candidates, (unsigned long long)cand);
         if (acc_n) atomicAdd(&counters->accepted, (unsigned long long)acc_n);
     }
@@ -835,6 +860,7 @@ struct sppm_ctx {
     bool force_coop = false;
     bool photon_coop = true;
     int newton_blocks_per_cu = 8;
+    int gather_blocks_per_cu = 4;
     bool verbose = false;
     DevBuf<uint32_t> bucket_of, hcount, hstart, cursor;
     DevBuf<PosKey> hp_pos; DevBuf<float4> hp_nr, hp_wgt, hp_tao; DevBuf<HpMeta> hp_meta;
@@ -843,6 +869,7 @@ struct sppm_ctx {
     // photon pass
     DevBuf<PosKey> depA, sdepA; DevBuf<DepB> depB, sdepB;
     DevBuf<uint32_t> dcount, dstart, scan_partial;
+    DevBuf<uint32_t> tile_ctr;                // gather tile counters, one per eighth of the tiles (64 B apart)
     DevBuf<unsigned long long> wave_chunks;   // {next, end} of the open deposit-slot chunk of every trace wave slot
     DevBuf<unsigned long long> scalars;   // [0] n_hits, [1] n_tasks_out, [2] next photon, [3] n_dep
     DevBuf<DevCounters> counters;
@@ -918,6 +945,7 @@ int sppm_create(sppm_ctx** out, int device_id) {
     if (const char* b = getenv("SPPM_COOP_THRESHOLD")) ctx->coop_threshold = (uint64_t)std::max(0ll, atoll(b));
     if (const char* b = getenv("SPPM_FORCE_COOP")) ctx->force_coop = atoi(b) != 0;
     if (const char* b = getenv("SPPM_PHOTON_COOP")) ctx->photon_coop = atoi(b) != 0;
+    if (const char* b = getenv("SPPM_GATHER_BPC")) ctx->gather_blocks_per_cu = std::max(1, atoi(b));
     if (const char* b = getenv("SPPM_NEWTON_BPC")) ctx->newton_blocks_per_cu = std::max(1, atoi(b));
     if (const char* b = getenv("SPPM_VERBOSE")) ctx->verbose = atoi(b) != 0;
     if (ctx->scalars.reserve(8) != hipSuccess || ctx->counters.reserve(1) != hipSuccess) {
@@ -938,7 +966,7 @@ void sppm_destroy(sppm_ctx* ctx) {
     ctx->bucket_of.release(); ctx->hcount.release(); ctx->hstart.release(); ctx->cursor.release();
     ctx->hp_pos.release(); ctx->hp_nr.release(); ctx->hp_wgt.release(); ctx->hp_tao.release(); ctx->hp_meta.release();
     ctx->depA.release(); ctx->sdepA.release(); ctx->depB.release(); ctx->sdepB.release();
-    ctx->wave_chunks.release();
+    ctx->wave_chunks.release(); ctx->tile_ctr.release();
     ctx->dcount.release(); ctx->dstart.release(); ctx->scan_partial.release(); ctx->scalars.release(); ctx->counters.release(); ctx->pic.release();
     if (ctx->ev[0]) (void)hipEventDestroy(ctx->ev[0]);
     if (ctx->ev[1]) (void)hipEventDestroy(ctx->ev[1]);
@@ -1277,10 +1305,12 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
         ctx->tm.deposit_sort_ms += toc(ctx);
         if (ctx->n_hp > 0) {
             tic(ctx);
-            const int waves = (int)((ctx->n_hp + 63) / 64);
-            const int blocks = (((waves + 3) / 4 + 7) / 8) * 8;   // a multiple of 8: the kernel deals blocks to XCDs
+            const uint64_t tiles = (ctx->n_hp + 63) / 64;
+            const int blocks = (int)std::max<uint64_t>(8, std::min<uint64_t>((uint64_t)ctx->num_cu * ctx->gather_blocks_per_cu, ((tiles + 3) / 4 + 7) / 8 * 8));
+            HIPCHK(ctx->tile_ctr.reserve(8 * 16));
+            HIPCHK(hipMemsetAsync(ctx->tile_ctr.p, 0, 8 * 16 * sizeof(uint32_t), ctx->stream));
             hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->hp_tao.p,
-                               (uint32_t)ctx->n_hp, ctx->dstart.p, ctx->sdepA.p, ctx->sdepB.p, ctx->grid, ctx->counters.p);
+                               (uint32_t)ctx->n_hp, ctx->dstart.p, ctx->sdepA.p, ctx->sdepB.p, ctx->grid, ctx->tile_ctr.p, ctx->counters.p);
             HIPCHK(hipGetLastError());
             ctx->tm.gather_ms += toc(ctx);
             ctx->tm.gather_launches++;
