@@ -64,6 +64,7 @@ struct SceneView {
     const DevObject* objs;      // LDS
     const double* patch_box;    // LDS, n_patches x 6 (pmin, pmax)
     const float* patch_cp;      // LDS, n_patches x 48
+    const float* patch_cp_global;   // the same table in global memory: wave-uniform reads of it become scalar loads
     const int* patch_obj;       // LDS, n_patches: owning object of each patch
     int n_objs;
     int n_patches;
@@ -153,11 +154,31 @@ __device__ __forceinline__ d3 rotated(d3 v, d3 a, double angle) {               
           v.z * (a.z * a.z + (1 - a.z * a.z) * cost);
     return r;
 }
-__device__ __forceinline__ d3 rand_refl(d3 n, double u1, double u2) {                      // Vec3.h:90-98
-    double theta = acos(sqrt(u1));
-    double phi = 2 * SPPM_PI * u2;
-    d3 ret = rotated(n, get_anormal(n), theta);
-    return get_unit(rotated(ret, n, phi));
+// Rodrigues rotation with the angle given by its cosine and sine (the body of Vec3::rotated, Vec3.h:102-114).
+__device__ __forceinline__ d3 rotated_cs(d3 v, d3 a, double cost, double sint) {
+    d3 r;
+    r.x = v.x * (a.x * a.x + (1 - a.x * a.x) * cost) + v.y * (a.x * a.y * (1 - cost) - a.z * sint) +
+          v.z * (a.x * a.z * (1 - cost) + a.y * sint);
+    r.y = v.x * (a.y * a.x * (1 - cost) + a.z * sint) + v.y * (a.y * a.y + (1 - a.y * a.y) * cost) +
+          v.z * (a.y * a.z * (1 - cost) - a.x * sint);
+    r.z = v.x * (a.z * a.x * (1 - cost) - a.y * sint) + v.y * (a.z * a.y * (1 - cost) + a.x * sint) +
+          v.z * (a.z * a.z + (1 - a.z * a.z) * cost);
+    return r;
+}
+// Vec3::GetUnitRandRefl, Vec3.h:90-98.  theta = acos(sqrt(u1)), so cos(theta) = sqrt(u1) and
+// sin(theta) = sqrt(1 - u1): the two square roots replace acos + cos + sin (equal to rounding).  The
+// |angle| < 1e-4 early return of Vec3::rotated needs theta < 1e-4, i.e. u1 > 1 - 1e-8, which a 24-bit
+// uniform never reaches; for phi it is kept.
+__device__ __forceinline__ d3 rand_refl(d3 n, double u1, double u2) {
+    const double cost = sqrt(u1), sint = sqrt(1.0 - u1);
+    const double phi = 2 * SPPM_PI * u2;
+    d3 ret = rotated_cs(n, get_anormal(n), cost, sint);
+    if (!(fabs(phi) < SPPM_EPS)) {
+        double sp, cp;
+        sincos(phi, &sp, &cp);
+        ret = rotated_cs(ret, n, cp, sp);
+    }
+    return get_unit(ret);
 }
 __device__ __forceinline__ d3 refracted(d3 I, d3 N, double n) {                            // Vec3.h:124-134
     double cosI = -dot(N, I);
@@ -294,10 +315,12 @@ __device__ __forceinline__ void newton_restart(const float* P, f3 o, f3 d, float
 // restarts, ties to the lowest restart (the reference keeps the first pushed
 // minimum).  o, d, sub (the ray's NEWTON hash state) and patch are wave-uniform.
 // Returns a wave-uniform (t,u,v); t = 1e20 when nothing converged.
-__device__ __forceinline__ void newton_coop(const float* __restrict__ cp_lds, int patch, f3 o, f3 d, uint32_t sub, float& rt, float& ru, float& rv) {
+// cp is the control-point table in GLOBAL memory: with a wave-uniform patch index the 48 reads are scalar
+// loads and the control points live in SGPRs for the whole solve (no vector registers spent on them).
+__device__ __forceinline__ void newton_coop(const float* __restrict__ cp, int patch, f3 o, f3 d, uint32_t sub, float& rt, float& ru, float& rv) {
     const int lane = lane_id();
     float P[48];
-    const float* src = cp_lds + patch * 48;
+    const float* src = cp + __builtin_amdgcn_readfirstlane(patch) * 48;
 #pragma unroll
     for (int k = 0; k < 48; k++) P[k] = src[k];
     float bt = (float)SPPM_MAX_NUM, bu = 0, bv = 0;
@@ -348,7 +371,7 @@ __device__ __forceinline__ void bezier_coop(const SceneView& S, const DevObject&
                 int pi = first_patch + base + (__ffsll((unsigned long long)pm) - 1);
                 pm &= pm - 1;
                 float t, u, v;
-                newton_coop(S.patch_cp, pi, fo, fd, ssub, t, u, v);
+                newton_coop(S.patch_cp_global, pi, fo, fd, ssub, t, u, v);
                 newton_calls += (lane == 0) ? 1u : 0u;
                 const float e = (float)SPPM_EPS;
                 // Bezier.h:251-259 (a patch whose minimum-t candidate is negative is dropped as a whole)

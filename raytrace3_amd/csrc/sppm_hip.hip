@@ -95,6 +95,7 @@ __device__ __forceinline__ SceneView stage_scene(const SceneParams& sp) {
     S.objs = (const DevObject*)base;
     S.patch_box = (const double*)(base + sp.off_box);
     S.patch_cp = (const float*)(base + sp.off_cp);
+    S.patch_cp_global = (const float*)(sp.blob + sp.off_cp);
     S.patch_obj = (const int*)(base + sp.off_pobj);
     S.n_objs = sp.n_objs;
     S.n_patches = sp.n_patches;
@@ -600,6 +601,9 @@ __global__ void k_close_chunks(const unsigned long long* __restrict__ wave_chunk
 #ifndef GATHER_ROWS
 #define GATHER_ROWS 6
 #endif
+#ifndef GATHER_TILE
+#define GATHER_TILE 16u      // HitPoints per tile (<= 64: one accumulator lane each)
+#endif
 
 // Sum over the 64 lanes, returned wave-uniform.
 __device__ __forceinline__ float wave_total_f(float v) {
@@ -619,7 +623,7 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
                                             const DepB* __restrict__ dB, const GridParams g, uint32_t& cand, uint32_t& acc_n) {
     const int lane = lane_id();
     const uint32_t mine = base + lane;
-    const bool valid = mine < n_hp;
+    const bool valid = (uint32_t)lane < GATHER_TILE && mine < n_hp;
     const PosKey mp = hp_pos[valid ? mine : base];
     const float4 mnr = hp_nr[valid ? mine : base];
     const float4 mw = hp_wgt[valid ? mine : base];
@@ -730,7 +734,7 @@ __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_po
                                                 const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
                                                 const uint32_t* __restrict__ dstart, const PosKey* __restrict__ dA,
                                                 const DepB* __restrict__ dB, GridParams g, uint32_t* tile_ctr, DevCounters* counters) {
-    const uint32_t n_tiles = (n_hp + 63u) >> 6;
+    const uint32_t n_tiles = (n_hp + GATHER_TILE - 1u) / GATHER_TILE;
     const uint32_t per = (n_tiles + 7u) >> 3;
     uint32_t cand = 0, acc_n = 0;   // wave-uniform tallies
     for (uint32_t s = 0; s < 8; s++) {
@@ -741,7 +745,7 @@ __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_po
             if (lane_id() == 0) t = atomicAdd(&tile_ctr[q * 16], 1u);
             t = bcast_u(t, 0) + q * per;
             if (t >= q_end) break;
-            gather_tile(t * 64u, hp_pos, hp_nr, hp_wgt, hp_tao, n_hp, dstart, dA, dB, g, cand, acc_n);
+            gather_tile(t * GATHER_TILE, hp_pos, hp_nr, hp_wgt, hp_tao, n_hp, dstart, dA, dB, g, cand, acc_n);
         }
     }
     if (lane_id() == 0) {
@@ -809,7 +813,7 @@ __global__ void __launch_bounds__(256) k_debug_newton(SceneParams sp, uint32_t n
         f3 fo = {(float)bcast_d(ox, src), (float)bcast_d(oy, src), (float)bcast_d(oz, src)};
         f3 fd = {(float)bcast_d(dx, src), (float)bcast_d(dy, src), (float)bcast_d(dz, src)};
         float t, u, v;
-        newton_coop(S.patch_cp, bcast_i(p, src), fo, fd, bcast_u(sub, src), t, u, v);
+        newton_coop(S.patch_cp_global, bcast_i(p, src), fo, fd, bcast_u(sub, src), t, u, v);
         if (lane == src && t < (float)SPPM_MAX_NUM) { mt = t; mu = u; mv = v; }
     }
     if (active) {
@@ -1305,7 +1309,7 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
         ctx->tm.deposit_sort_ms += toc(ctx);
         if (ctx->n_hp > 0) {
             tic(ctx);
-            const uint64_t tiles = (ctx->n_hp + 63) / 64;
+            const uint64_t tiles = (ctx->n_hp + GATHER_TILE - 1) / GATHER_TILE;
             const int blocks = (int)std::max<uint64_t>(8, std::min<uint64_t>((uint64_t)ctx->num_cu * ctx->gather_blocks_per_cu, ((tiles + 3) / 4 + 7) / 8 * 8));
             HIPCHK(ctx->tile_ctr.reserve(8 * 16));
             HIPCHK(hipMemsetAsync(ctx->tile_ctr.p, 0, 8 * 16 * sizeof(uint32_t), ctx->stream));
