@@ -403,6 +403,10 @@ __device__ __forceinline__ void near_consider(Near& n, double dist, int obj, int
 
 // Planes and spheres (Obj.h:65-85, :111-139), per lane, fp64.
 __device__ __forceinline__ void analytic_nearest(const SceneView& S, bool active, d3 o, d3 d, Near& nr) {
+#ifdef ABLATE_ANALYTIC
+    if (active) near_consider(nr, 10.0 + d.x, d.y > 0 ? 3 : 0, 0, -1, 0, 0, 0);
+    return;
+#endif
     for (int a = 0; a < S.n_objs; a++) {
         const DevObject& ob = S.objs[a];
         const int type = __builtin_amdgcn_readfirstlane(ob.type);   // wave-uniform: keep the branch scalar
@@ -428,6 +432,9 @@ __device__ __forceinline__ void analytic_nearest(const SceneView& S, bool active
 
 // Bezier objects, solved inside the calling wave (Bezier.h:240-282).
 __device__ __forceinline__ void bezier_nearest_coop(const SceneView& S, bool active, d3 o, d3 d, uint32_t newton_sub, Near& nr, uint32_t& newton_calls) {
+#ifdef ABLATE_BEZIER
+    return;
+#endif
     for (int a = 0; a < S.n_objs; a++) {
         const DevObject& ob = S.objs[a];
         if (__builtin_amdgcn_readfirstlane(ob.type) != OBJ_BEZIER) continue;
@@ -495,6 +502,10 @@ __device__ __forceinline__ Hit finish_hit(const SceneView& S, d3 o, d3 d, const 
         const DevObject& ob = S.objs[nr.obj];
         h.pos = o + d * nr.dist;
         h.color[0] = ob.color[0]; h.color[1] = ob.color[1]; h.color[2] = ob.color[2];
+#ifdef ABLATE_TEX
+        if (ob.type == OBJ_PLANE) { h.n = ld3(ob.n); return h; }
+        if (ob.type == OBJ_SPHERE) { h.n = get_unit(h.pos - ld3(ob.p0)); return h; }
+#endif
         if (ob.type == OBJ_PLANE) {
             h.n = ld3(ob.n);
             if (ob.texture >= 0) {                                                        // Obj.h:86-100

@@ -53,7 +53,7 @@ struct SceneParams {
 };
 
 struct DevCounters {
-    unsigned long long photons, segments, deposits, candidates, accepted, newton_calls, eye_segments;
+    unsigned long long photons, segments, deposits, candidates, accepted, newton_calls, eye_segments, hits;
     unsigned int overflow;   // bit0 hitpoint capacity, bit1 eye task queue, bit2 deposit capacity
     unsigned int pad;
 };
@@ -138,6 +138,30 @@ __device__ __forceinline__ unsigned long long wave_alloc_n(uint32_t n, unsigned 
     return base + (inc - n);
 }
 
+// Output slots (deposits, raw HitPoints) are claimed from the global counter a chunk at a time and
+// handed out inside the wave: [next, end) is the wave's open chunk (wave-uniform).  Every lane calls
+// this; lanes with want = true get distinct slots.  A claim that does not fit the open chunk uses up
+// its rest and continues in a fresh chunk, so only the last chunk of a wave slot is left partly unused.
+__device__ __forceinline__ unsigned long long chunk_alloc(bool want, unsigned long long& next, unsigned long long& end,
+                                                          unsigned long long* counter, unsigned long long chunk) {
+    const uint64_t m = __ballot(want);
+    if (m == 0) return 0;
+    const unsigned long long need = (unsigned long long)__popcll(m), left = end - next;
+    const unsigned long long rank = (unsigned long long)__popcll(m & lanemask_lt());
+    unsigned long long slot = next + rank;
+    if (need > left) {
+        unsigned long long base = 0;
+        if (lane_id() == 0) base = atomicAdd(counter, chunk);
+        base = bcast_u64(base, 0);
+        if (rank >= left) slot = base + (rank - left);
+        next = base + (need - left);
+        end = base + chunk;
+    } else {
+        next += need;
+    }
+    return slot;
+}
+
 enum { MODE_EYE = 0, MODE_PHOTON = 1 };
 #define TRACE_WORK_CHUNK 128u     // work items a wave claims per atomic on the work counter
 #define TRACE_SLOT_CHUNK 256u     // deposit slots a wave claims per atomic on the deposit counter
@@ -186,16 +210,14 @@ __global__ void __launch_bounds__(256, COOP ? 2 : 3) k_trace(SceneParams sp, Tra
     int dep = 0, node = 0;
     Near nr;
     near_init(nr);
-    uint32_t ncalls = 0, nseg = 0, ndep = 0, nphot = 0;
+    uint32_t ncalls = 0, nseg = 0, ndep = 0, nphot = 0, nhit = 0;
     // Work items and deposit slots are claimed from the global counters a chunk at a time (all waves
     // hammering one address with a returned atomic per loop iteration serialises the whole grid).
     unsigned long long work_next = 0, work_end = 0;     // this wave's claimed work items, wave-uniform
-    unsigned long long slot_next = 0, slot_end = 0;     // this wave's claimed deposit slots, wave-uniform
+    unsigned long long slot_next = 0, slot_end = 0;     // this wave's open chunk of output slots (deposits / raw HitPoints), wave-uniform
     const uint32_t wave_slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (MODE == MODE_PHOTON) {
-        slot_next = tp.wave_chunks[2 * wave_slot];
-        slot_end = tp.wave_chunks[2 * wave_slot + 1];
-    }
+    slot_next = tp.wave_chunks[2 * wave_slot];
+    slot_end = tp.wave_chunks[2 * wave_slot + 1];
     for (;;) {
         // ---- refill idle lanes
         const uint64_t idle = __ballot(!active);
@@ -380,8 +402,9 @@ __global__ void __launch_bounds__(256, COOP ? 2 : 3) k_trace(SceneParams sp, Tra
                     active = false;
                 }
             }
-            const unsigned long long hs = wave_alloc(emit_hp, tp.n_hits);
+            const unsigned long long hs = chunk_alloc(emit_hp, slot_next, slot_end, tp.n_hits, TRACE_SLOT_CHUNK);
             if (emit_hp) {
+                nhit++;
                 if (hs < tp.hit_cap) tp.hits[hs] = rh;
                 else atomicOr(&tp.counters->overflow, 1u);
             }
@@ -411,7 +434,11 @@ __global__ void __launch_bounds__(256, COOP ? 2 : 3) k_trace(SceneParams sp, Tra
                 d3 nd;
                 if (ob.diffr > r) {                                                       // DIFF, Raytracer.h:163-166
                     const uint32_t ds = rng_sub(tp.rng, id, vertex, P_DIFFUSE);
+#ifdef ABLATE_BOUNCE
+                    nd = get_unit(hit.n + mk(rng_u01(ds, 0) - 0.5, rng_u01(ds, 1) - 0.5, 0.1));
+#else
                     nd = rand_refl(hit.n, rng_u01(ds, 0), rng_u01(ds, 1));
+#endif
                 } else if (ob.diffr + ob.reflr > r) {                                     // REFL, Raytracer.h:177-181
                     nd = get_unit(get_refl(d, hit.n));
                 } else {                                                                  // REFR, Raytracer.h:182-190
@@ -422,39 +449,24 @@ __global__ void __launch_bounds__(256, COOP ? 2 : 3) k_trace(SceneParams sp, Tra
                 o = hit.pos; d = nd;
                 if (dep > SPPM_MAX_DEP) active = false;                                   // Raytracer.h:126-133
             }
-            const uint64_t dm = __ballot(dp);
-            if (dm) {
-                const unsigned long long need = (unsigned long long)__popcll(dm);
-                const unsigned long long left = slot_end - slot_next;
-                const unsigned long long rank = (unsigned long long)__popcll(dm & lanemask_lt());
-                unsigned long long slot = slot_next + rank;
-                if (need > left) {   // the chunk runs out inside this wave-step: the first `left` lanes finish it, the rest open a new one
-                    unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(tp.n_dep, (unsigned long long)TRACE_SLOT_CHUNK);
-                    base = bcast_u64(base, 0);
-                    if (rank >= left) slot = base + (rank - left);
-                    slot_next = base + (need - left);
-                    slot_end = base + TRACE_SLOT_CHUNK;
-                } else {
-                    slot_next += need;
-                }
-                if (dp) {
-                    ndep++;
-                    if (slot < tp.dep_cap) {
-                        tp.depA[slot] = da; tp.depB[slot] = db;
-                        atomicAdd(&tp.dcount[db.bucket & 0xffffffu], 1u);
-                    } else atomicOr(&tp.counters->overflow, 4u);
-                }
+            const unsigned long long slot = chunk_alloc(dp, slot_next, slot_end, tp.n_dep, TRACE_SLOT_CHUNK);
+            if (dp) {
+                ndep++;
+                if (slot < tp.dep_cap) {
+                    tp.depA[slot] = da; tp.depB[slot] = db;
+                    atomicAdd(&tp.dcount[db.bucket & 0xffffffu], 1u);
+                } else atomicOr(&tp.counters->overflow, 4u);
             }
         }
     }
-    if (MODE == MODE_PHOTON && lane == 0) {   // the open chunk stays with this wave slot for the next launch of the batch
+    if (lane == 0) {   // the open chunk stays with this wave slot for the next launch of the pass / batch
         tp.wave_chunks[2 * wave_slot] = slot_next;
         tp.wave_chunks[2 * wave_slot + 1] = slot_end;
     }
     flush_counter(&tp.counters->newton_calls, ncalls);
     if (MODE == MODE_EYE) {
         flush_counter(&tp.counters->eye_segments, nseg);
+        flush_counter(&tp.counters->hits, nhit);
     } else {
         flush_counter(&tp.counters->segments, nseg);
         flush_counter(&tp.counters->deposits, ndep);
@@ -484,6 +496,7 @@ __global__ void __launch_bounds__(256) k_newton(const ParkRec* __restrict__ park
 __global__ void k_hp_count(const RawHit* hits, uint32_t n, GridParams g, uint32_t* bucket_of, uint32_t* count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (hits[i].pix < 0) { bucket_of[i] = 0xffffffffu; return; }   // a claimed but unused slot
     uint64_t key = cell_key(ld3(hits[i].pos), g.inv_cs);
     uint32_t b = key_bucket(key, g.mask);
     bucket_of[i] = b;
@@ -550,8 +563,9 @@ __global__ void k_hp_scatter(const RawHit* hits, uint32_t n, GridParams g, const
                              uint32_t* cursor, PosKey* hp_pos, float4* hp_nr, float4* hp_wgt, float4* hp_tao, HpMeta* hp_meta) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const RawHit h = hits[i];
     uint32_t b = bucket_of[i];
+    if (b == 0xffffffffu) return;
+    const RawHit h = hits[i];
     uint32_t s = start[b] + atomicAdd(&cursor[b], 1u);
     PosKey pk; pk.x = h.pos[0]; pk.y = h.pos[1]; pk.z = h.pos[2]; pk.key = cell_key(ld3(h.pos), g.inv_cs);
     hp_pos[s] = pk;
@@ -576,14 +590,17 @@ __global__ void k_dep_scatter(const PosKey* depA, const DepB* depB, const unsign
     }
 }
 
-// Marks the unused tail of every wave slot's open chunk as holes (run once per batch, after the
-// last trace launch, before the deposits are sorted).
-__global__ void k_close_chunks(const unsigned long long* __restrict__ wave_chunks, uint32_t n_slots, DepB* depB, unsigned long long cap) {
+// Marks the unused tail of every wave slot's open chunk as holes (run once per eye pass / photon batch,
+// after the last trace launch, before the records are sorted).  Exactly one of depB / hits is set.
+__global__ void k_close_chunks(const unsigned long long* __restrict__ wave_chunks, uint32_t n_slots, DepB* depB, RawHit* hits, unsigned long long cap) {
     const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (w >= n_slots) return;
     const unsigned long long a = wave_chunks[2 * w], b = wave_chunks[2 * w + 1];
     for (unsigned long long h = a + lane_id(); h < b; h += 64)
-        if (h < cap) depB[h].bucket = DEP_HOLE;
+        if (h < cap) {
+            if (depB) depB[h].bucket = DEP_HOLE;
+            else hits[h].pix = -1;
+        }
 }
 
 // ------------------------------------------------------------------ gather
@@ -1122,11 +1139,11 @@ static int begin_deposit_batch(sppm_ctx* ctx) {
     HIPCHK(hipGetLastError());
     return SPPM_OK;
 }
-// Turns the unused tails of the open chunks into holes once the batch's trace launches are done.
-static int end_deposit_batch(sppm_ctx* ctx, uint64_t dep_cap) {
+// Turns the unused tails of the open chunks into holes once the trace launches of a batch / pass are done.
+static int close_chunks(sppm_ctx* ctx, DepB* depB, RawHit* hits, uint64_t cap) {
     const uint32_t n_slots = (uint32_t)trace_max_blocks(ctx) * 4u;
-    hipLaunchKernelGGL(k_close_chunks, dim3((n_slots + 3) / 4), dim3(256), 0, ctx->stream, ctx->wave_chunks.p, n_slots, ctx->depB.p,
-                       (unsigned long long)dep_cap);
+    hipLaunchKernelGGL(k_close_chunks, dim3((n_slots + 3) / 4), dim3(256), 0, ctx->stream, ctx->wave_chunks.p, n_slots, depB, hits,
+                       (unsigned long long)cap);
     HIPCHK(hipGetLastError());
     return SPPM_OK;
 }
@@ -1209,21 +1226,26 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
     ctx->cam = *cam;
     ctx->have_eye = false;
     const uint64_t npx = (uint64_t)cam->w * cam->h;
-    uint64_t hit_cap = std::max<uint64_t>(2 * npx, 1 << 16);
+    uint64_t hit_cap = std::max<uint64_t>(2 * npx, 1 << 16) + dep_slack(ctx);
     ctx->tm = sppm_timings{};
+    const size_t n_slots = (size_t)trace_max_blocks(ctx) * 4;
+    HIPCHK(ctx->wave_chunks.reserve(2 * n_slots));
     for (int attempt = 0;; attempt++) {
         HIPCHK(ctx->raw.reserve(hit_cap));
         HIPCHK(hipMemsetAsync(ctx->scalars.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->counters.p, 0, sizeof(DevCounters), ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->wave_chunks.p, 0, 2 * n_slots * sizeof(unsigned long long), ctx->stream));
         tic(ctx);
         TraceParams tp{};
         for (int k = 0; k < 3; k++) { tp.pos[k] = cam->pos[k]; tp.dir[k] = cam->dir[k]; tp.du[k] = cam->du[k]; tp.dv[k] = cam->dv[k]; }
         tp.w = cam->w; tp.h = cam->h;
         tp.hits = ctx->raw.p; tp.n_hits = ctx->scalars.p + SC_HITS; tp.hit_cap = hit_cap;
         tp.counters = ctx->counters.p;
+        tp.wave_chunks = ctx->wave_chunks.p;
         tp.rng = host_rng_base(seed, replica * 4u + D_EYE);
         int launches = 0;
-        const int rc = run_rounds(ctx, MODE_EYE, tp, 0, npx, &launches);
+        int rc = run_rounds(ctx, MODE_EYE, tp, 0, npx, &launches);
+        if (rc == SPPM_OK) rc = close_chunks(ctx, nullptr, ctx->raw.p, hit_cap);
         ctx->tm.eye_trace_ms = toc(ctx);
         ctx->tm.trace_launches = launches;
         if (rc == SPPM_OK) break;
@@ -1231,9 +1253,14 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
         if (attempt == 5) return fail(ctx, SPPM_E_CAPACITY, "HitPoint buffer overflowed after 5 capacity doublings");
         hit_cap *= 2;
     }
-    unsigned long long nh = 0;
-    HIPCHK(hipMemcpy(&nh, ctx->scalars.p + SC_HITS, sizeof(nh), hipMemcpyDeviceToHost));
-    ctx->n_hp = nh;
+    // claimed slots of the raw array (with holes) and the number of HitPoints in them
+    unsigned long long claimed = 0;
+    DevCounters dc;
+    HIPCHK(hipMemcpyAsync(&claimed, ctx->scalars.p + SC_HITS, sizeof(claimed), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&dc, ctx->counters.p, sizeof(dc), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    claimed = std::min<unsigned long long>(claimed, hit_cap);
+    ctx->n_hp = dc.hits;
     // ---- hashed grid over HitPoints
     const uint64_t n = ctx->n_hp;
     const double cs = std::sqrt(SPPM_INIT_R2) * 1.0001;   // cell >= search radius: neighbours within +-1 cell
@@ -1241,7 +1268,7 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
     const uint32_t M = std::min<uint32_t>(1u << 22, std::max<uint32_t>(1u << 16, next_pow2(2 * std::max<uint64_t>(n, 1))));
     ctx->grid.mask = M - 1;
     tic(ctx);
-    HIPCHK(ctx->bucket_of.reserve(std::max<uint64_t>(n, 1)));
+    HIPCHK(ctx->bucket_of.reserve(std::max<uint64_t>(claimed, 1)));
     HIPCHK(ctx->hcount.reserve(M + 1)); HIPCHK(ctx->hstart.reserve(M + 1)); HIPCHK(ctx->cursor.reserve(M + 1));
     HIPCHK(ctx->dcount.reserve(M + 1)); HIPCHK(ctx->dstart.reserve(M + 1));
     HIPCHK(ctx->hp_pos.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_nr.reserve(std::max<uint64_t>(n, 1)));
@@ -1250,10 +1277,10 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
     if (int rc = launch_fill(ctx, ctx->hcount.p, M + 1, 0)) return rc;
     if (int rc = launch_fill(ctx, ctx->cursor.p, M + 1, 0)) return rc;
     if (n > 0) {
-        const int blocks = (int)((n + 255) / 256);
-        hipLaunchKernelGGL(k_hp_count, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)n, ctx->grid, ctx->bucket_of.p, ctx->hcount.p);
+        const int blocks = (int)((claimed + 255) / 256);
+        hipLaunchKernelGGL(k_hp_count, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)claimed, ctx->grid, ctx->bucket_of.p, ctx->hcount.p);
         if (int rc = launch_scan(ctx, ctx->hcount.p, ctx->hstart.p, M)) return rc;
-        hipLaunchKernelGGL(k_hp_scatter, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)n, ctx->grid, ctx->bucket_of.p,
+        hipLaunchKernelGGL(k_hp_scatter, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)claimed, ctx->grid, ctx->bucket_of.p,
                            ctx->hstart.p, ctx->cursor.p, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->hp_tao.p, ctx->hp_meta.p);
         HIPCHK(hipGetLastError());
     }
@@ -1299,7 +1326,7 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
         if (int rc = launch_fill(ctx, ctx->cursor.p, M + 1, 0)) return rc;
         tic(ctx);
         if (int rc = run_rounds(ctx, MODE_PHOTON, tp, first, count, nullptr)) return rc;
-        if (int rc = end_deposit_batch(ctx, dep_cap)) return rc;
+        if (int rc = close_chunks(ctx, ctx->depB.p, nullptr, dep_cap)) return rc;
         ctx->tm.photon_trace_ms += toc(ctx);
         tic(ctx);
         if (int rc = launch_scan(ctx, ctx->dcount.p, ctx->dstart.p, M)) return rc;
@@ -1450,7 +1477,7 @@ int sppm_debug_photon_deposits(sppm_ctx* ctx, uint64_t rounds, uint32_t per_roun
     ctx->counters.p = scratch_counters.p;   // run_rounds polls the overflow bits of the counters in use
     int rrc = run_rounds(ctx, MODE_PHOTON, tp, photon_begin, count, nullptr);
     ctx->counters.p = saved;
-    if (rrc == SPPM_OK) rrc = end_deposit_batch(ctx, dep_cap);
+    if (rrc == SPPM_OK) rrc = close_chunks(ctx, ctx->depB.p, nullptr, dep_cap);
     unsigned long long nd = 0;
     hipError_t e = hipMemcpyAsync(&nd, ctx->scalars.p + SC_DEP, sizeof(nd), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
