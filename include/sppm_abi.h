@@ -140,7 +140,8 @@ typedef struct sppm_counters {
     uint64_t eye_segments;   /* eye path segments traced */
 } sppm_counters;
 
-/* HIP-event timings (ms) of the kernels launched by the last eye / photon pass. */
+/* HIP-event timings (ms), measured on the context's stream, of everything queued since
+ * the last sppm_eye_pass call (sppm_get_timings waits for the stream). */
 typedef struct sppm_timings {
     double eye_trace_ms;
     double grid_build_ms;
@@ -187,6 +188,13 @@ int sppm_resolve(sppm_ctx* ctx, double* pic_hw3, int accumulate);
 /* Same, into a caller-provided DEVICE buffer of h*w*3 floats (overwritten) so a
  * collective (RCCL all-reduce of the flux image) can run on it in place. */
 int sppm_resolve_device(sppm_ctx* ctx, float* dev_pic_hw3);
+
+/* sppm_photon_pass and sppm_resolve_device only QUEUE their kernels on the context's stream
+ * (the reference is synchronous; a GPU host wants to keep queueing).  sppm_synchronize waits
+ * for everything queued and returns the error, if any, that a queued pass ran into (a ray /
+ * task / deposit queue overflow: SPPM_E_CAPACITY).  sppm_resolve, sppm_get_counters and the
+ * next sppm_eye_pass report such an error as well.  No counterpart in the reference. */
+int sppm_synchronize(sppm_ctx* ctx);
 
 /* Copy out up to cap HitPoints; *n receives |Hvec|. */
 int sppm_get_hitpoints(sppm_ctx* ctx, sppm_hitpoint* out, uint64_t cap, uint64_t* n);

@@ -95,6 +95,7 @@ ABI_SYMBOLS = {
     "sppm_photon_pass": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]),
     "sppm_resolve": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
     "sppm_resolve_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sppm_synchronize": (C.c_int, [C.c_void_p]),
     "sppm_get_hitpoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "sppm_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "sppm_get_timings": (C.c_int, [C.c_void_p, C.POINTER(Timings)]),
@@ -181,6 +182,10 @@ class SppmContext:
         assert pic.shape == (h, w, 3) and pic.dtype == np.float64 and pic.flags.c_contiguous
         self._check(self.lib.sppm_resolve(self._ctx, _dptr(pic), 1 if accumulate_into is not None else 0), "sppm_resolve")
         return pic
+
+    def synchronize(self):
+        """Wait for the queued passes; raises if one of them overflowed a queue."""
+        self._check(self.lib.sppm_synchronize(self._ctx), "sppm_synchronize")
 
     def resolve_device(self, dev_ptr):
         self._check(self.lib.sppm_resolve_device(self._ctx, C.c_void_p(dev_ptr)), "sppm_resolve_device")

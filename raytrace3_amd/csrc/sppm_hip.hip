@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -170,7 +171,7 @@ enum { MODE_EYE = 0, MODE_PHOTON = 1 };
 struct TraceParams {
     // work items: [0, n_resume) = park records of the previous round, then fresh_count fresh
     // items (pixels for the eye pass, photon indices for the photon pass)
-    const ParkRec* resume; unsigned long long n_resume;
+    const ParkRec* resume; const unsigned long long* n_resume_dev;   // park records of the previous round and their count (device)
     const NewtonTask* tasks_in; const float4* res_in;
     unsigned long long fresh_first, fresh_count;
     unsigned long long* next;
@@ -200,9 +201,12 @@ struct TraceParams {
 // from its record.  This keeps the 50 x 10 Newton iterations out of the divergent path loop.
 template <int MODE, bool COOP>
 __global__ void __launch_bounds__(256, COOP ? 2 : 3) k_trace(SceneParams sp, TraceParams tp) {
+    const unsigned long long n_resume = tp.resume ? *tp.n_resume_dev : 0ull;
+    const unsigned long long total = n_resume + tp.fresh_count;
+    // the host sizes a resume launch without knowing its count: workgroups beyond the work leave at once
+    if (blockIdx.x > 0 && (unsigned long long)blockIdx.x * blockDim.x >= total) return;
     SceneView S = stage_scene(sp);
     const int lane = lane_id();
-    const unsigned long long total = tp.n_resume + tp.fresh_count;
     bool active = false, pending = false, exhausted = (total == 0);
     d3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     float carry[3] = {0, 0, 0};
@@ -238,7 +242,7 @@ __global__ void __launch_bounds__(256, COOP ? 2 : 3) k_trace(SceneParams sp, Tra
             if (!active && rank < avail) {
                 active = true;
                 pending = false;
-                if (my < tp.n_resume) {
+                if (my < n_resume) {
                     const ParkRec r = tp.resume[my];
                     o = ld3(r.o); d = ld3(r.d);
                     carry[0] = r.carry[0]; carry[1] = r.carry[1]; carry[2] = r.carry[2];
@@ -250,7 +254,7 @@ __global__ void __launch_bounds__(256, COOP ? 2 : 3) k_trace(SceneParams sp, Tra
                         tfirst = r.task_first; tcount = r.task_count;
                     }
                 } else {
-                    const unsigned long long g = tp.fresh_first + (my - tp.n_resume);
+                    const unsigned long long g = tp.fresh_first + (my - n_resume);
                     id = (uint32_t)g; dep = 0; node = 0;
                     if (MODE == MODE_EYE) {
                         const int row = (int)(g / (unsigned long long)tp.w), col = (int)(g % (unsigned long long)tp.w);
@@ -476,8 +480,10 @@ __global__ void __launch_bounds__(256, COOP ? 2 : 3) k_trace(SceneParams sp, Tra
 
 // Bezier3::newton (Bezier.h:112-159) for every task of a round: one wave per (ray, patch),
 // lane r < 50 = restart r, control points read from global memory with a wave-uniform address.
-__global__ void __launch_bounds__(256) k_newton(const ParkRec* __restrict__ park, const NewtonTask* __restrict__ tasks, uint32_t n_tasks,
+__global__ void __launch_bounds__(256) k_newton(const ParkRec* __restrict__ park, const NewtonTask* __restrict__ tasks,
+                                                const unsigned long long* __restrict__ n_tasks_dev, unsigned long long task_cap,
                                                 const float* __restrict__ patches, float4* __restrict__ res, DevCounters* counters) {
+    const uint32_t n_tasks = (uint32_t)min(*n_tasks_dev, task_cap);
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     uint32_t done = 0;
     for (uint32_t t = wave; t < n_tasks; t += n_waves) {
@@ -863,6 +869,7 @@ uint32_t next_pow2(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p
 
 }  // namespace
 
+#define CTL_SCALARS 16
 struct sppm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -883,22 +890,36 @@ struct sppm_ctx {
     int newton_blocks_per_cu = 8;
     int gather_blocks_per_cu = 4;
     bool verbose = false;
-    DevBuf<uint32_t> bucket_of, hcount, hstart, cursor;
+    DevBuf<uint32_t> bucket_of, hstart;
+    DevBuf<uint32_t> hist;                // HitPoint histogram | scatter cursors | deposit histogram, (M + 1) words each
+    uint32_t* hcount() const { return hist.p; }
+    uint32_t* cursor() const { return hist.p + ((size_t)grid.mask + 2); }
+    uint32_t* dcount() const { return hist.p + 2 * ((size_t)grid.mask + 2); }
+    bool has_dual_lobe = false;           // some material reflects and refracts: eye paths branch
     DevBuf<PosKey> hp_pos; DevBuf<float4> hp_nr, hp_wgt, hp_tao; DevBuf<HpMeta> hp_meta;
     uint64_t n_hp = 0;
     GridParams grid{};
     // photon pass
     DevBuf<PosKey> depA, sdepA; DevBuf<DepB> depB, sdepB;
-    DevBuf<uint32_t> dcount, dstart, scan_partial;
-    DevBuf<uint32_t> tile_ctr;                // gather tile counters, one per eighth of the tiles (64 B apart)
-    DevBuf<unsigned long long> wave_chunks;   // {next, end} of the open deposit-slot chunk of every trace wave slot
-    DevBuf<unsigned long long> scalars;   // [0] n_hits, [1] n_tasks_out, [2] next photon, [3] n_dep
+    DevBuf<uint32_t> dstart, scan_partial;
+    // Control block, one allocation so that one memset resets a pass: queue scalars (CTL_SCALARS x u64) |
+    // gather tile counters (8 x 16 u32, 64 B apart) | {next, end} of the open output chunk of every trace wave slot
+    DevBuf<unsigned long long> ctl;
+    unsigned long long* scalars() const { return ctl.p; }
+    uint32_t* tile_ctr() const { return (uint32_t*)(ctl.p + CTL_SCALARS); }
+    unsigned long long* wave_chunks() const { return ctl.p + CTL_SCALARS + 64; }
+    size_t ctl_words() const { return CTL_SCALARS + 64 + 2 * (size_t)num_cu * 4 * 4; }
     DevBuf<DevCounters> counters;
+    bool check_pending = false;           // launches since the last look at the overflow flags
     DevBuf<float> pic;
     uint64_t last_rounds = 0, last_per_round = 0;
     uint64_t batch = 1u << 20;
-    sppm_timings tm{};
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    // HIP-event spans on the stream, read back (and only then waited for) by sppm_get_timings
+    struct Span { int phase; hipEvent_t a, b; };
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<Span> spans;
+    int gather_launches = 0, trace_launches = 0;
     int num_cu = 256;
 
     SceneParams scene_params() const {
@@ -932,14 +953,28 @@ static uint32_t host_rng_base(uint64_t seed, uint32_t stream) {
     return h;
 }
 
-static void tic(sppm_ctx* ctx) { (void)hipEventRecord(ctx->ev[0], ctx->stream); }
-static double toc(sppm_ctx* ctx) {
-    (void)hipEventRecord(ctx->ev[1], ctx->stream);
-    (void)hipEventSynchronize(ctx->ev[1]);
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
-    return (double)ms;
+enum { PH_EYE = 0, PH_GRID, PH_TRACE, PH_SORT, PH_GATHER, PH_RESOLVE, PH_COUNT };
+static hipEvent_t next_event(sppm_ctx* ctx) {
+    if (ctx->ev_used == ctx->ev_pool.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        ctx->ev_pool.push_back(e);
+    }
+    return ctx->ev_pool[ctx->ev_used++];
 }
+// Opens / closes a timed span on the stream.  Nothing waits here: the events are read in sppm_get_timings.
+static void tic(sppm_ctx* ctx, int phase) {
+    sppm_ctx::Span sp{phase, next_event(ctx), nullptr};
+    if (sp.a) (void)hipEventRecord(sp.a, ctx->stream);
+    ctx->spans.push_back(sp);
+}
+static void toc(sppm_ctx* ctx) {
+    if (ctx->spans.empty()) return;
+    sppm_ctx::Span& sp = ctx->spans.back();
+    sp.b = next_event(ctx);
+    if (sp.b) (void)hipEventRecord(sp.b, ctx->stream);
+}
+static void drop_spans(sppm_ctx* ctx) { ctx->spans.clear(); ctx->ev_used = 0; ctx->gather_launches = ctx->trace_launches = 0; }
 
 extern "C" {
 
@@ -954,8 +989,7 @@ int sppm_create(sppm_ctx** out, int device_id) {
     ctx->device = device_id;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
-    if (hipStreamCreate(&ctx->stream) != hipSuccess || hipEventCreate(&ctx->ev[0]) != hipSuccess ||
-        hipEventCreate(&ctx->ev[1]) != hipSuccess) {
+    if (hipStreamCreate(&ctx->stream) != hipSuccess) {
         delete ctx;
         return SPPM_E_DEVICE;
     }
@@ -969,10 +1003,12 @@ int sppm_create(sppm_ctx** out, int device_id) {
     if (const char* b = getenv("SPPM_GATHER_BPC")) ctx->gather_blocks_per_cu = std::max(1, atoi(b));
     if (const char* b = getenv("SPPM_NEWTON_BPC")) ctx->newton_blocks_per_cu = std::max(1, atoi(b));
     if (const char* b = getenv("SPPM_VERBOSE")) ctx->verbose = atoi(b) != 0;
-    if (ctx->scalars.reserve(8) != hipSuccess || ctx->counters.reserve(1) != hipSuccess) {
+    if (ctx->ctl.reserve(ctx->ctl_words()) != hipSuccess || ctx->counters.reserve(1) != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return SPPM_E_DEVICE;
     }
+    (void)hipMemset(ctx->ctl.p, 0, ctx->ctl_words() * sizeof(unsigned long long));
     (void)hipMemset(ctx->counters.p, 0, sizeof(DevCounters));
     *out = ctx;
     return SPPM_OK;
@@ -984,13 +1020,11 @@ void sppm_destroy(sppm_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->blob.release(); ctx->tex.release(); ctx->texels.release(); ctx->lights.release();
     ctx->raw.release(); ctx->park[0].release(); ctx->park[1].release(); ctx->ntask[0].release(); ctx->ntask[1].release(); ctx->nres.release();
-    ctx->bucket_of.release(); ctx->hcount.release(); ctx->hstart.release(); ctx->cursor.release();
+    ctx->bucket_of.release(); ctx->hist.release(); ctx->hstart.release();
     ctx->hp_pos.release(); ctx->hp_nr.release(); ctx->hp_wgt.release(); ctx->hp_tao.release(); ctx->hp_meta.release();
     ctx->depA.release(); ctx->sdepA.release(); ctx->depB.release(); ctx->sdepB.release();
-    ctx->wave_chunks.release(); ctx->tile_ctr.release();
-    ctx->dcount.release(); ctx->dstart.release(); ctx->scan_partial.release(); ctx->scalars.release(); ctx->counters.release(); ctx->pic.release();
-    if (ctx->ev[0]) (void)hipEventDestroy(ctx->ev[0]);
-    if (ctx->ev[1]) (void)hipEventDestroy(ctx->ev[1]);
+    ctx->dstart.release(); ctx->scan_partial.release(); ctx->ctl.release(); ctx->counters.release(); ctx->pic.release();
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1029,6 +1063,7 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
                 if (b[3 + c] < v) b[3 + c] = v;
             }
     }
+    bool dual_lobe = false;
     for (int i = 0; i < no; i++) {
         const sppm_object& so = s->objects[i];
         DevObject& o = objs[i];
@@ -1050,6 +1085,7 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
         o.flags = (any_zero3(so.material.diff) ? 0 : F_DIFF) | (any_zero3(so.material.refl) ? 0 : F_REFL) |
                   (any_zero3(so.material.refr) ? 0 : F_REFR);
         o.first_patch = so.first_patch; o.n_patches = so.n_patches; o.pad = 0;
+        if ((o.flags & F_REFL) && (o.flags & F_REFR)) dual_lobe = true;
         if (so.type == SPPM_OBJ_BEZIER) {
             if (so.first_patch < 0 || so.n_patches < 0 || so.first_patch + so.n_patches > np)
                 return fail(ctx, SPPM_E_INVALID, "bezier object indexes patches out of range");
@@ -1094,6 +1130,7 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
     HIPCHK(ctx->lights.reserve(dl.size()));
     HIPCHK(hipMemcpy(ctx->lights.p, dl.data(), dl.size() * sizeof(DevLight), hipMemcpyHostToDevice));
     ctx->n_lights = s->n_lights;
+    ctx->has_dual_lobe = dual_lobe;
     ctx->have_scene = true;
     ctx->have_eye = false;
     return SPPM_OK;
@@ -1121,28 +1158,21 @@ static int launch_scan(sppm_ctx* ctx, const uint32_t* cnt, uint32_t* start, uint
 
 }  // extern "C" (templates below need C++ linkage)
 
-// scalars: device-side counters shared by the passes
-enum { SC_HITS = 0, SC_NEXT = 2, SC_DEP = 3, SC_PARK0 = 4, SC_TASK0 = 5, SC_PARK1 = 6, SC_TASK1 = 7 };
+// queue scalars of the control block
+enum { SC_HITS = 0, SC_DEP = 1, SC_NEXT0 = 2 /* .. SC_NEXT0 + 3 */, SC_PARK0 = 6, SC_TASK0 = 7, SC_PARK1 = 8, SC_TASK1 = 9 };
 
 static int trace_max_blocks(const sppm_ctx* ctx) { return ctx->num_cu * 4; }
-// deposit slots that can be left unused in open chunks (one chunk per wave slot of the largest trace grid)
+// output slots that can be left unused in open chunks (one chunk per wave slot of the largest trace grid)
 static uint64_t dep_slack(const sppm_ctx* ctx) { return (uint64_t)trace_max_blocks(ctx) * 4u * TRACE_SLOT_CHUNK; }
 
-// Resets the deposit queue of a batch: slot counter, per-wave open chunks, bucket histogram.
-static int begin_deposit_batch(sppm_ctx* ctx) {
-    const uint32_t M = ctx->grid.mask + 1;
-    const size_t n_slots = (size_t)trace_max_blocks(ctx) * 4;
-    HIPCHK(ctx->wave_chunks.reserve(2 * n_slots));
-    HIPCHK(hipMemsetAsync(ctx->scalars.p + SC_DEP, 0, sizeof(unsigned long long), ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->wave_chunks.p, 0, 2 * n_slots * sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, ctx->stream, ctx->dcount.p, (size_t)M + 1, 0u);
-    HIPCHK(hipGetLastError());
+static int reset_ctl(sppm_ctx* ctx) {
+    HIPCHK(hipMemsetAsync(ctx->ctl.p, 0, ctx->ctl_words() * sizeof(unsigned long long), ctx->stream));
     return SPPM_OK;
 }
 // Turns the unused tails of the open chunks into holes once the trace launches of a batch / pass are done.
 static int close_chunks(sppm_ctx* ctx, DepB* depB, RawHit* hits, uint64_t cap) {
     const uint32_t n_slots = (uint32_t)trace_max_blocks(ctx) * 4u;
-    hipLaunchKernelGGL(k_close_chunks, dim3((n_slots + 3) / 4), dim3(256), 0, ctx->stream, ctx->wave_chunks.p, n_slots, depB, hits,
+    hipLaunchKernelGGL(k_close_chunks, dim3((n_slots + 3) / 4), dim3(256), 0, ctx->stream, ctx->wave_chunks(), n_slots, depB, hits,
                        (unsigned long long)cap);
     HIPCHK(hipGetLastError());
     return SPPM_OK;
@@ -1153,64 +1183,112 @@ static void launch_trace(sppm_ctx* ctx, bool coop, int blocks, const SceneParams
     if (coop) hipLaunchKernelGGL((k_trace<MODE, true>), dim3(blocks), dim3(256), (size_t)ctx->blob_bytes, ctx->stream, sp, tp);
     else hipLaunchKernelGGL((k_trace<MODE, false>), dim3(blocks), dim3(256), (size_t)ctx->blob_bytes, ctx->stream, sp, tp);
 }
+static int launch_trace_mode(sppm_ctx* ctx, int mode, bool coop, int blocks, const TraceParams& tp) {
+    const SceneParams sp = ctx->scene_params();
+    if (mode == MODE_EYE) launch_trace<MODE_EYE>(ctx, coop, blocks, sp, tp);
+    else launch_trace<MODE_PHOTON>(ctx, coop, blocks, sp, tp);
+    HIPCHK(hipGetLastError());
+    ctx->trace_launches++;
+    ctx->check_pending = true;
+    return SPPM_OK;
+}
 
-// Runs one set of fresh work items (pixels or photons) to completion: trace -> [newton ->
-// resume trace]* until no ray is parked.  tp carries the pass-specific outputs.
-static int run_rounds(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_first, uint64_t fresh_count, int* launches) {
+// What the host reads back when it has to look at the queues.
+struct QueueState { unsigned long long sc[CTL_SCALARS]; DevCounters dc; };
+static int read_queues(sppm_ctx* ctx, QueueState& q) {
+    HIPCHK(hipMemcpyAsync(q.sc, ctx->scalars(), sizeof(q.sc), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&q.dc, ctx->counters.p, sizeof(q.dc), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->check_pending = false;
+    return SPPM_OK;
+}
+#define SPPM_RETRY_HITS (SPPM_E_CAPACITY + 100)
+static int overflow_code(sppm_ctx* ctx, const DevCounters& dc) {
+    if (dc.overflow == 0) return SPPM_OK;
+    (void)hipMemsetAsync(&ctx->counters.p->overflow, 0, sizeof(unsigned int), ctx->stream);   // seen: clear
+    if (dc.overflow & 6u) return fail(ctx, SPPM_E_CAPACITY, "a ray / task / deposit queue overflowed");
+    return SPPM_RETRY_HITS;   // HitPoint buffer too small: the eye pass retries with more room
+}
+
+// Traces one set of fresh work items (pixels or photons) to completion.  The control block must have
+// been reset.  The launches are queued without looking at their results wherever the schedule is known
+// in advance:
+//   in-wave Bezier solves (photons by default): one launch, nothing can be parked;
+//   parked solves (eye rays by default): trace -> k_newton -> resume launch with in-wave solves, the
+//     counts travelling in device memory.  Only a material with both a reflective and a refractive lobe
+//     can leave rays queued after that (the refraction branches of Raytracer.h:327-336); then, and in
+//     the non-default modes, the host reads the queue counters and keeps launching until they are empty.
+// *synced is set when the host has waited for the stream (q then holds the final queue state).
+static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_first, uint64_t fresh_count, bool has_dual_lobe,
+                     bool need_final_state, QueueState& q, bool* synced) {
+    *synced = false;
     const uint64_t park_cap = std::max<uint64_t>(fresh_count, 1u << 16);
     const uint64_t task_cap = 16 * park_cap;
     if (task_cap > 0xffffffffull) return fail(ctx, SPPM_E_CAPACITY, "too many work items for one round");
     HIPCHK(ctx->park[0].reserve(park_cap)); HIPCHK(ctx->park[1].reserve(park_cap));
     HIPCHK(ctx->ntask[0].reserve(task_cap)); HIPCHK(ctx->ntask[1].reserve(task_cap));
     HIPCHK(ctx->nres.reserve(task_cap));
-    const SceneParams sp = ctx->scene_params();
-    unsigned long long* sc = ctx->scalars.p;
-    HIPCHK(hipMemsetAsync(sc + SC_NEXT, 0, sizeof(unsigned long long), ctx->stream));
-    HIPCHK(hipMemsetAsync(sc + SC_PARK0, 0, 4 * sizeof(unsigned long long), ctx->stream));
-    tp.next = sc + SC_NEXT;
-    tp.park_cap = park_cap; tp.task_cap = task_cap;
-    tp.resume = nullptr; tp.n_resume = 0; tp.tasks_in = nullptr; tp.res_in = nullptr;
-    tp.fresh_first = fresh_first; tp.fresh_count = fresh_count;
+    unsigned long long* sc = ctx->scalars();
     const int max_blocks = trace_max_blocks(ctx);
     auto blocks_for = [&](uint64_t items) { return (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)max_blocks, (items + 255) / 256)); };
-    int cur = 0;
-    tp.park_out = ctx->park[0].p; tp.n_park = sc + SC_PARK0; tp.tasks_out = ctx->ntask[0].p; tp.n_tasks = sc + SC_TASK0;
+    auto park_ctr = [&](int i) { return sc + (i ? SC_PARK1 : SC_PARK0); };
+    auto task_ctr = [&](int i) { return sc + (i ? SC_TASK1 : SC_TASK0); };
+    int next_slot = 0;   // work counters SC_NEXT0.. are zero after the reset; later launches clear theirs first
+    auto set_round = [&](int cur, bool fresh) -> int {   // cur: queue the launch reads (ignored when fresh); writes the other one
+        const int out = fresh ? 0 : (cur ^ 1);
+        if (next_slot < 4) tp.next = sc + SC_NEXT0 + next_slot++;
+        else { tp.next = sc + SC_NEXT0; HIPCHK(hipMemsetAsync(tp.next, 0, sizeof(unsigned long long), ctx->stream)); }
+        if (fresh) {
+            tp.resume = nullptr; tp.n_resume_dev = nullptr; tp.tasks_in = nullptr; tp.res_in = nullptr;
+            tp.fresh_first = fresh_first; tp.fresh_count = fresh_count;
+        } else {
+            tp.resume = ctx->park[cur].p; tp.n_resume_dev = park_ctr(cur); tp.tasks_in = ctx->ntask[cur].p; tp.res_in = ctx->nres.p;
+            tp.fresh_first = 0; tp.fresh_count = 0;
+        }
+        tp.park_out = ctx->park[out].p; tp.n_park = park_ctr(out); tp.tasks_out = ctx->ntask[out].p; tp.n_tasks = task_ctr(out);
+        return SPPM_OK;
+    };
+    auto launch_newton = [&](int cur) -> int {
+        hipLaunchKernelGGL(k_newton, dim3(ctx->num_cu * ctx->newton_blocks_per_cu), dim3(256), 0, ctx->stream, ctx->park[cur].p,
+                           ctx->ntask[cur].p, task_ctr(cur), (unsigned long long)task_cap, (const float*)(ctx->blob.p + ctx->off_cp),
+                           ctx->nres.p, ctx->counters.p);
+        HIPCHK(hipGetLastError());
+        return SPPM_OK;
+    };
+    tp.park_cap = park_cap; tp.task_cap = task_cap;
     // Eye rays that meet a Bezier object are neighbours in the image, so whole waves would stall in the
     // in-wave solve while others idle: they are parked and solved by k_newton.  Photons meet it at random,
     // a few lanes per wave: solving in place costs less than the extra launches of a park round.
-    bool coop = ctx->force_coop || (mode == MODE_PHOTON && ctx->photon_coop);
-    if (mode == MODE_EYE) launch_trace<MODE_EYE>(ctx, coop, blocks_for(fresh_count), sp, tp);
-    else launch_trace<MODE_PHOTON>(ctx, coop, blocks_for(fresh_count), sp, tp);
-    HIPCHK(hipGetLastError());
-    if (launches) (*launches)++;
-    for (int round = 0; round < 256; round++) {
-        unsigned long long q[2];
-        DevCounters dc;
-        HIPCHK(hipMemcpyAsync(q, sc + (cur ? SC_PARK1 : SC_PARK0), sizeof(q), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(&dc, ctx->counters.p, sizeof(dc), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        if (dc.overflow & 1u) return SPPM_E_CAPACITY + 100;   // HitPoint buffer too small: the caller retries with more room
-        if (dc.overflow & 6u) return fail(ctx, SPPM_E_CAPACITY, "a ray / task / deposit queue overflowed");
-        const unsigned long long n_park = q[0], n_tasks = q[1];
-        if (ctx->verbose) fprintf(stderr, "[sppm] mode %d round %d: parked %llu rays, %llu newton tasks\n", mode, round, n_park, n_tasks);
-        if (n_park == 0) return SPPM_OK;
-        if (n_tasks > 0) {
-            const int nb = (int)std::min<uint64_t>((n_tasks + 3) / 4, (uint64_t)ctx->num_cu * ctx->newton_blocks_per_cu);
-            hipLaunchKernelGGL(k_newton, dim3(nb), dim3(256), 0, ctx->stream, ctx->park[cur].p, ctx->ntask[cur].p, (uint32_t)n_tasks,
-                               (const float*)(ctx->blob.p + ctx->off_cp), ctx->nres.p, ctx->counters.p);
+    const bool first_coop = ctx->force_coop || (mode == MODE_PHOTON && ctx->photon_coop);
+    const bool legacy = (mode == MODE_PHOTON && !first_coop);   // photons with parked solves: every round looks at the counters
+    if (int rc = set_round(0, true)) return rc;
+    if (int rc = launch_trace_mode(ctx, mode, first_coop, blocks_for(fresh_count), tp)) return rc;
+    int cur = 0;   // queue written by the last launch
+    if (!legacy) {
+        if (!first_coop) {
+            if (int rc = launch_newton(0)) return rc;
+            if (int rc = set_round(0, false)) return rc;
+            // the count is unknown here: a generous grid, of which the workgroups beyond the work leave at once
+            if (int rc = launch_trace_mode(ctx, mode, true, std::max(1, blocks_for(fresh_count) / 2), tp)) return rc;
+            cur = 1;
         }
+        const bool may_queue = (mode == MODE_EYE && has_dual_lobe);
+        if (!may_queue && !need_final_state) return SPPM_OK;
+    }
+    for (int round = 0; round < 256; round++) {
+        if (int rc = read_queues(ctx, q)) return rc;
+        *synced = true;
+        if (int rc = overflow_code(ctx, q.dc)) return rc;
+        const unsigned long long n_park = q.sc[cur ? SC_PARK1 : SC_PARK0], n_tasks = q.sc[cur ? SC_TASK1 : SC_TASK0];
+        if (ctx->verbose) fprintf(stderr, "[sppm] mode %d round %d: %llu rays queued, %llu newton tasks\n", mode, round, n_park, n_tasks);
+        if (n_park == 0) return SPPM_OK;
+        if (n_tasks > 0) if (int rc = launch_newton(cur)) return rc;
         const int nxt = cur ^ 1;
-        HIPCHK(hipMemsetAsync(sc + SC_NEXT, 0, sizeof(unsigned long long), ctx->stream));
-        HIPCHK(hipMemsetAsync(sc + (nxt ? SC_PARK1 : SC_PARK0), 0, 2 * sizeof(unsigned long long), ctx->stream));
-        tp.resume = ctx->park[cur].p; tp.n_resume = n_park; tp.tasks_in = ctx->ntask[cur].p; tp.res_in = ctx->nres.p;
-        tp.fresh_first = 0; tp.fresh_count = 0;
-        tp.park_out = ctx->park[nxt].p; tp.n_park = sc + (nxt ? SC_PARK1 : SC_PARK0);
-        tp.tasks_out = ctx->ntask[nxt].p; tp.n_tasks = sc + (nxt ? SC_TASK1 : SC_TASK0);
-        coop = ctx->force_coop || (mode == MODE_PHOTON && ctx->photon_coop) || n_park < ctx->coop_threshold;
-        if (mode == MODE_EYE) launch_trace<MODE_EYE>(ctx, coop, blocks_for(n_park), sp, tp);
-        else launch_trace<MODE_PHOTON>(ctx, coop, blocks_for(n_park), sp, tp);
-        HIPCHK(hipGetLastError());
-        if (launches) (*launches)++;
+        HIPCHK(hipMemsetAsync(park_ctr(nxt), 0, sizeof(unsigned long long), ctx->stream));
+        HIPCHK(hipMemsetAsync(task_ctr(nxt), 0, sizeof(unsigned long long), ctx->stream));
+        if (int rc = set_round(cur, false)) return rc;
+        const bool coop = !legacy || ctx->force_coop || n_park < ctx->coop_threshold;
+        if (int rc = launch_trace_mode(ctx, mode, coop, blocks_for(n_park), tp)) return rc;
         cur = nxt;
     }
     return fail(ctx, SPPM_E_DEVICE, "trace rounds did not drain");
@@ -1227,64 +1305,58 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
     ctx->have_eye = false;
     const uint64_t npx = (uint64_t)cam->w * cam->h;
     uint64_t hit_cap = std::max<uint64_t>(2 * npx, 1 << 16) + dep_slack(ctx);
-    ctx->tm = sppm_timings{};
-    const size_t n_slots = (size_t)trace_max_blocks(ctx) * 4;
-    HIPCHK(ctx->wave_chunks.reserve(2 * n_slots));
+    drop_spans(ctx);
+    QueueState q{};
     for (int attempt = 0;; attempt++) {
         HIPCHK(ctx->raw.reserve(hit_cap));
-        HIPCHK(hipMemsetAsync(ctx->scalars.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
-        HIPCHK(hipMemsetAsync(ctx->counters.p, 0, sizeof(DevCounters), ctx->stream));
-        HIPCHK(hipMemsetAsync(ctx->wave_chunks.p, 0, 2 * n_slots * sizeof(unsigned long long), ctx->stream));
-        tic(ctx);
+        // the tallies restart; the overflow flags stay until the host has looked at them
+        HIPCHK(hipMemsetAsync(ctx->counters.p, 0, offsetof(DevCounters, overflow), ctx->stream));
+        if (int rc = reset_ctl(ctx)) return rc;
+        tic(ctx, PH_EYE);
         TraceParams tp{};
         for (int k = 0; k < 3; k++) { tp.pos[k] = cam->pos[k]; tp.dir[k] = cam->dir[k]; tp.du[k] = cam->du[k]; tp.dv[k] = cam->dv[k]; }
         tp.w = cam->w; tp.h = cam->h;
-        tp.hits = ctx->raw.p; tp.n_hits = ctx->scalars.p + SC_HITS; tp.hit_cap = hit_cap;
+        tp.hits = ctx->raw.p; tp.n_hits = ctx->scalars() + SC_HITS; tp.hit_cap = hit_cap;
         tp.counters = ctx->counters.p;
-        tp.wave_chunks = ctx->wave_chunks.p;
+        tp.wave_chunks = ctx->wave_chunks();
         tp.rng = host_rng_base(seed, replica * 4u + D_EYE);
-        int launches = 0;
-        int rc = run_rounds(ctx, MODE_EYE, tp, 0, npx, &launches);
-        if (rc == SPPM_OK) rc = close_chunks(ctx, nullptr, ctx->raw.p, hit_cap);
-        ctx->tm.eye_trace_ms = toc(ctx);
-        ctx->tm.trace_launches = launches;
+        bool synced = false;
+        int rc = run_trace(ctx, MODE_EYE, tp, 0, npx, ctx->has_dual_lobe, true, q, &synced);
+        toc(ctx);
         if (rc == SPPM_OK) break;
-        if (rc != SPPM_E_CAPACITY + 100) return rc;
+        if (rc != SPPM_RETRY_HITS) return rc;
         if (attempt == 5) return fail(ctx, SPPM_E_CAPACITY, "HitPoint buffer overflowed after 5 capacity doublings");
         hit_cap *= 2;
+        drop_spans(ctx);
     }
-    // claimed slots of the raw array (with holes) and the number of HitPoints in them
-    unsigned long long claimed = 0;
-    DevCounters dc;
-    HIPCHK(hipMemcpyAsync(&claimed, ctx->scalars.p + SC_HITS, sizeof(claimed), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(&dc, ctx->counters.p, sizeof(dc), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    claimed = std::min<unsigned long long>(claimed, hit_cap);
-    ctx->n_hp = dc.hits;
+    // q is the state after the last launch: claimed slots of the raw array (with holes) and the HitPoints in them
+    const unsigned long long claimed = std::min<unsigned long long>(q.sc[SC_HITS], hit_cap);
+    ctx->n_hp = q.dc.hits;
     // ---- hashed grid over HitPoints
     const uint64_t n = ctx->n_hp;
     const double cs = std::sqrt(SPPM_INIT_R2) * 1.0001;   // cell >= search radius: neighbours within +-1 cell
     ctx->grid.inv_cs = 1.0 / cs;
     const uint32_t M = std::min<uint32_t>(1u << 22, std::max<uint32_t>(1u << 16, next_pow2(2 * std::max<uint64_t>(n, 1))));
     ctx->grid.mask = M - 1;
-    tic(ctx);
+    tic(ctx, PH_GRID);
+    if (int rc = close_chunks(ctx, nullptr, ctx->raw.p, hit_cap)) return rc;
     HIPCHK(ctx->bucket_of.reserve(std::max<uint64_t>(claimed, 1)));
-    HIPCHK(ctx->hcount.reserve(M + 1)); HIPCHK(ctx->hstart.reserve(M + 1)); HIPCHK(ctx->cursor.reserve(M + 1));
-    HIPCHK(ctx->dcount.reserve(M + 1)); HIPCHK(ctx->dstart.reserve(M + 1));
+    // hcount | cursor | dcount are one allocation: a pass clears two neighbours with one fill
+    HIPCHK(ctx->hist.reserve(3 * ((size_t)M + 1)));
+    HIPCHK(ctx->hstart.reserve(M + 1)); HIPCHK(ctx->dstart.reserve(M + 1));
     HIPCHK(ctx->hp_pos.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_nr.reserve(std::max<uint64_t>(n, 1)));
     HIPCHK(ctx->hp_wgt.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_tao.reserve(std::max<uint64_t>(n, 1)));
     HIPCHK(ctx->hp_meta.reserve(std::max<uint64_t>(n, 1)));
-    if (int rc = launch_fill(ctx, ctx->hcount.p, M + 1, 0)) return rc;
-    if (int rc = launch_fill(ctx, ctx->cursor.p, M + 1, 0)) return rc;
+    if (int rc = launch_fill(ctx, ctx->hcount(), 2 * ((size_t)M + 1), 0)) return rc;
     if (n > 0) {
         const int blocks = (int)((claimed + 255) / 256);
-        hipLaunchKernelGGL(k_hp_count, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)claimed, ctx->grid, ctx->bucket_of.p, ctx->hcount.p);
-        if (int rc = launch_scan(ctx, ctx->hcount.p, ctx->hstart.p, M)) return rc;
+        hipLaunchKernelGGL(k_hp_count, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)claimed, ctx->grid, ctx->bucket_of.p, ctx->hcount());
+        if (int rc = launch_scan(ctx, ctx->hcount(), ctx->hstart.p, M)) return rc;
         hipLaunchKernelGGL(k_hp_scatter, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)claimed, ctx->grid, ctx->bucket_of.p,
-                           ctx->hstart.p, ctx->cursor.p, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->hp_tao.p, ctx->hp_meta.p);
+                           ctx->hstart.p, ctx->cursor(), ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->hp_tao.p, ctx->hp_meta.p);
         HIPCHK(hipGetLastError());
     }
-    ctx->tm.grid_build_ms = toc(ctx);
+    toc(ctx);
     ctx->have_eye = true;
     ctx->last_rounds = 0; ctx->last_per_round = 0;
     return SPPM_OK;
@@ -1293,10 +1365,29 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
 static void fill_photon_params(sppm_ctx* ctx, TraceParams& tp, uint32_t per_round, uint64_t dep_cap, uint64_t seed, uint32_t replica,
                                DevCounters* counters) {
     tp.lights = ctx->lights.p; tp.n_lights = ctx->n_lights; tp.per_round = per_round;
-    tp.depA = ctx->depA.p; tp.depB = ctx->depB.p; tp.n_dep = ctx->scalars.p + SC_DEP; tp.dep_cap = dep_cap;
-    tp.dcount = ctx->dcount.p; tp.grid = ctx->grid; tp.counters = counters;
-    tp.wave_chunks = ctx->wave_chunks.p;
+    tp.depA = ctx->depA.p; tp.depB = ctx->depB.p; tp.n_dep = ctx->scalars() + SC_DEP; tp.dep_cap = dep_cap;
+    tp.dcount = ctx->dcount(); tp.grid = ctx->grid; tp.counters = counters;
+    tp.wave_chunks = ctx->wave_chunks();
     tp.rng = host_rng_base(seed, replica * 4u + D_PHOTON);
+}
+
+// Deferred look at the overflow flags of the launches queued since the last look.
+static int check_deferred(sppm_ctx* ctx) {
+    if (!ctx->check_pending) return SPPM_OK;
+    DevCounters dc;
+    HIPCHK(hipMemcpyAsync(&dc, ctx->counters.p, sizeof(dc), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->check_pending = false;
+    if (overflow_code(ctx, dc) != SPPM_OK) return fail(ctx, SPPM_E_CAPACITY, "a ray / task / deposit queue overflowed in an earlier pass");
+    return SPPM_OK;
+}
+
+int sppm_synchronize(sppm_ctx* ctx) {
+    if (!ctx) return SPPM_E_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->check_pending) return check_deferred(ctx);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SPPM_OK;
 }
 
 int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_t photon_begin, uint64_t photon_count,
@@ -1315,40 +1406,36 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
     const uint64_t dep_cap = batch * (SPPM_MAX_DEP + 1) + dep_slack(ctx);
     HIPCHK(ctx->depA.reserve(dep_cap)); HIPCHK(ctx->depB.reserve(dep_cap));
     HIPCHK(ctx->sdepA.reserve(dep_cap)); HIPCHK(ctx->sdepB.reserve(dep_cap));
-    HIPCHK(ctx->wave_chunks.reserve(2 * (size_t)trace_max_blocks(ctx) * 4));
     TraceParams tp{};
     fill_photon_params(ctx, tp, per_round, dep_cap, seed, replica, ctx->counters.p);
-    ctx->tm.photon_trace_ms = ctx->tm.deposit_sort_ms = ctx->tm.gather_ms = 0;
-    ctx->tm.gather_launches = 0;
+    QueueState q{};
     for (uint64_t first = photon_begin; first < end; first += batch) {
         const uint64_t count = std::min(batch, end - first);
-        if (int rc = begin_deposit_batch(ctx)) return rc;
-        if (int rc = launch_fill(ctx, ctx->cursor.p, M + 1, 0)) return rc;
-        tic(ctx);
-        if (int rc = run_rounds(ctx, MODE_PHOTON, tp, first, count, nullptr)) return rc;
+        if (int rc = reset_ctl(ctx)) return rc;
+        if (int rc = launch_fill(ctx, ctx->cursor(), 2 * ((size_t)M + 1), 0)) return rc;   // cursor and dcount
+        tic(ctx, PH_TRACE);
+        bool synced = false;
+        if (int rc = run_trace(ctx, MODE_PHOTON, tp, first, count, false, false, q, &synced)) return rc;
         if (int rc = close_chunks(ctx, ctx->depB.p, nullptr, dep_cap)) return rc;
-        ctx->tm.photon_trace_ms += toc(ctx);
-        tic(ctx);
-        if (int rc = launch_scan(ctx, ctx->dcount.p, ctx->dstart.p, M)) return rc;
-        hipLaunchKernelGGL(k_dep_scatter, dim3(ctx->num_cu * 8), dim3(256), 0, ctx->stream, ctx->depA.p, ctx->depB.p, ctx->scalars.p + SC_DEP,
-                           dep_cap, ctx->dstart.p, ctx->cursor.p, ctx->sdepA.p, ctx->sdepB.p);
+        toc(ctx);
+        tic(ctx, PH_SORT);
+        if (int rc = launch_scan(ctx, ctx->dcount(), ctx->dstart.p, M)) return rc;
+        hipLaunchKernelGGL(k_dep_scatter, dim3(ctx->num_cu * 8), dim3(256), 0, ctx->stream, ctx->depA.p, ctx->depB.p, ctx->scalars() + SC_DEP,
+                           dep_cap, ctx->dstart.p, ctx->cursor(), ctx->sdepA.p, ctx->sdepB.p);
         HIPCHK(hipGetLastError());
-        ctx->tm.deposit_sort_ms += toc(ctx);
+        toc(ctx);
         if (ctx->n_hp > 0) {
-            tic(ctx);
+            tic(ctx, PH_GATHER);
             const uint64_t tiles = (ctx->n_hp + GATHER_TILE - 1) / GATHER_TILE;
             const int blocks = (int)std::max<uint64_t>(8, std::min<uint64_t>((uint64_t)ctx->num_cu * ctx->gather_blocks_per_cu, ((tiles + 3) / 4 + 7) / 8 * 8));
-            HIPCHK(ctx->tile_ctr.reserve(8 * 16));
-            HIPCHK(hipMemsetAsync(ctx->tile_ctr.p, 0, 8 * 16 * sizeof(uint32_t), ctx->stream));
             hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->hp_tao.p,
-                               (uint32_t)ctx->n_hp, ctx->dstart.p, ctx->sdepA.p, ctx->sdepB.p, ctx->grid, ctx->tile_ctr.p, ctx->counters.p);
+                               (uint32_t)ctx->n_hp, ctx->dstart.p, ctx->sdepA.p, ctx->sdepB.p, ctx->grid, ctx->tile_ctr(), ctx->counters.p);
             HIPCHK(hipGetLastError());
-            ctx->tm.gather_ms += toc(ctx);
-            ctx->tm.gather_launches++;
+            toc(ctx);
+            ctx->gather_launches++;
         }
     }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return SPPM_OK;
+    return SPPM_OK;   // queued; a queue overflow, if any, is reported by the next call that waits for the stream
 }
 
 int sppm_resolve_device(sppm_ctx* ctx, float* dev_pic) {
@@ -1357,7 +1444,7 @@ int sppm_resolve_device(sppm_ctx* ctx, float* dev_pic) {
     if (ctx->last_rounds == 0) return fail(ctx, SPPM_E_INVALID, "sppm_photon_pass must come first");
     HIPCHK(hipSetDevice(ctx->device));
     const size_t npx = (size_t)ctx->cam.w * ctx->cam.h;
-    tic(ctx);
+    tic(ctx, PH_RESOLVE);
     HIPCHK(hipMemsetAsync(dev_pic, 0, npx * 3 * sizeof(float), ctx->stream));
     if (ctx->n_hp > 0) {
         const double inv_norm = 1.0 / SPPM_PI / ((double)ctx->last_rounds * (double)ctx->last_per_round);
@@ -1366,7 +1453,7 @@ int sppm_resolve_device(sppm_ctx* ctx, float* dev_pic) {
                            inv_norm, dev_pic);
         HIPCHK(hipGetLastError());
     }
-    ctx->tm.resolve_ms = toc(ctx);
+    toc(ctx);
     return SPPM_OK;
 }
 
@@ -1380,6 +1467,7 @@ int sppm_resolve(sppm_ctx* ctx, double* pic, int accumulate) {
     std::vector<float> h(n);
     HIPCHK(hipMemcpyAsync(h.data(), ctx->pic.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (int rc = check_deferred(ctx)) return rc;
     if (accumulate) for (size_t i = 0; i < n; i++) pic[i] += (double)h[i];
     else for (size_t i = 0; i < n; i++) pic[i] = (double)h[i];
     return SPPM_OK;
@@ -1417,16 +1505,29 @@ int sppm_get_counters(sppm_ctx* ctx, sppm_counters* out) {
     if (!ctx || !out) return SPPM_E_INVALID;
     HIPCHK(hipSetDevice(ctx->device));
     DevCounters dc;
-    HIPCHK(hipMemcpy(&dc, ctx->counters.p, sizeof(dc), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(&dc, ctx->counters.p, sizeof(dc), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     out->photons = dc.photons; out->segments = dc.segments; out->deposits = dc.deposits;
     out->candidates = dc.candidates; out->accepted = dc.accepted; out->hitpoints = ctx->n_hp;
     out->newton_calls = dc.newton_calls; out->eye_segments = dc.eye_segments;
+    ctx->check_pending = false;
+    if (overflow_code(ctx, dc) != SPPM_OK) return fail(ctx, SPPM_E_CAPACITY, "a ray / task / deposit queue overflowed in an earlier pass");
     return SPPM_OK;
 }
 
+// Waits for the stream and sums the spans recorded since the last sppm_eye_pass call.
 int sppm_get_timings(sppm_ctx* ctx, sppm_timings* out) {
     if (!ctx || !out) return SPPM_E_INVALID;
-    *out = ctx->tm;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    double ms[PH_COUNT] = {0, 0, 0, 0, 0, 0};
+    for (const sppm_ctx::Span& sp : ctx->spans) {
+        float t = 0;
+        if (sp.a && sp.b && hipEventElapsedTime(&t, sp.a, sp.b) == hipSuccess) ms[sp.phase] += (double)t;
+    }
+    out->eye_trace_ms = ms[PH_EYE]; out->grid_build_ms = ms[PH_GRID]; out->photon_trace_ms = ms[PH_TRACE];
+    out->deposit_sort_ms = ms[PH_SORT]; out->gather_ms = ms[PH_GATHER]; out->resolve_ms = ms[PH_RESOLVE];
+    out->gather_launches = ctx->gather_launches; out->trace_launches = ctx->trace_launches;
     return SPPM_OK;
 }
 
@@ -1466,22 +1567,27 @@ int sppm_debug_photon_deposits(sppm_ctx* ctx, uint64_t rounds, uint32_t per_roun
     const uint64_t dep_cap = count * (SPPM_MAX_DEP + 1) + dep_slack(ctx);
     HIPCHK(ctx->depA.reserve(dep_cap)); HIPCHK(ctx->depB.reserve(dep_cap));
     HIPCHK(ctx->sdepA.reserve(dep_cap)); HIPCHK(ctx->sdepB.reserve(dep_cap));
-    HIPCHK(ctx->wave_chunks.reserve(2 * (size_t)trace_max_blocks(ctx) * 4));
+    if (int rc = check_deferred(ctx)) return rc;
     DevBuf<DevCounters> scratch_counters;   // keep the pass counters untouched
     HIPCHK(scratch_counters.reserve(1));
     HIPCHK(hipMemsetAsync(scratch_counters.p, 0, sizeof(DevCounters), ctx->stream));
     TraceParams tp{};
     fill_photon_params(ctx, tp, per_round, dep_cap, seed, replica, scratch_counters.p);
-    if (int rc = begin_deposit_batch(ctx)) { scratch_counters.release(); return rc; }
+    const uint32_t M = ctx->grid.mask + 1;
+    int rrc = reset_ctl(ctx);
+    if (rrc == SPPM_OK) rrc = launch_fill(ctx, ctx->dcount(), (size_t)M + 1, 0);
     DevCounters* saved = ctx->counters.p;
-    ctx->counters.p = scratch_counters.p;   // run_rounds polls the overflow bits of the counters in use
-    int rrc = run_rounds(ctx, MODE_PHOTON, tp, photon_begin, count, nullptr);
+    ctx->counters.p = scratch_counters.p;   // the trace driver reads the overflow bits of the counters in use
+    QueueState q{};
+    bool synced = false;
+    if (rrc == SPPM_OK) rrc = run_trace(ctx, MODE_PHOTON, tp, photon_begin, count, false, true, q, &synced);
     ctx->counters.p = saved;
     if (rrc == SPPM_OK) rrc = close_chunks(ctx, ctx->depB.p, nullptr, dep_cap);
     unsigned long long nd = 0;
-    hipError_t e = hipMemcpyAsync(&nd, ctx->scalars.p + SC_DEP, sizeof(nd), hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipMemcpyAsync(&nd, ctx->scalars() + SC_DEP, sizeof(nd), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     scratch_counters.release();
+    ctx->check_pending = false;
     if (rrc != SPPM_OK) return rrc;
     if (e != hipSuccess) return fail(ctx, SPPM_E_DEVICE, hipGetErrorString(e));
     // nd counts claimed slots; unused ones are holes
