@@ -68,6 +68,24 @@ def cpu_baseline(scene, w, h, rounds, threads):
     }
 
 
+def measured_traffic():
+    """HBM bytes per k_gather launch from the rocprofv3 PMC passes committed under profiles/
+    ((2 * FETCH_SIZE + WRITE_SIZE) * 1024, collected by tools/gpu_profile.sh on this same command);
+    None when no such profile is in the tree."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+            t = d.get("k_gather", {}).get("hbm_traffic_bytes_per_launch")
+            if t:
+                best = (float(t), os.path.basename(f))
+        except (OSError, ValueError):
+            pass
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,28 +135,26 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    acc = {k: 0.0 for k in ("eye_trace_ms", "grid_build_ms", "photon_trace_ms", "deposit_sort_ms", "gather_ms", "resolve_ms")}
-    gather_launches = 0
-    bytes_model = 0.0
+    ctx.stats_mode(True)        # counters and HIP-event spans accumulate over the timed steps: no per-step readback
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
-        tm = ctx.timings()          # HIP-event durations measured on the library's stream
-        for k in acc:
-            acc[k] += tm[k]
-        gather_launches += tm["gather_launches"]
-        c = ctx.counters()
-        bytes_model += 40.0 * c["candidates"] + 32.0 * c["accepted"] + 64.0 * c["segments"]
+    ctx.synchronize()           # waits for the library's stream and raises if a queued pass overflowed
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    counters = ctx.counters()
+    tm = ctx.timings()              # HIP-event durations measured on the library's stream, summed over the timed steps
+    counters = ctx.counters()       # tallies of the timed steps
+    acc = {k: tm[k] for k in ("eye_trace_ms", "grid_build_ms", "photon_trace_ms", "deposit_sort_ms", "gather_ms", "resolve_ms")}
+    gather_launches = tm["gather_launches"]
+    bytes_model = 40.0 * counters["candidates"] + 32.0 * counters["accepted"] + 64.0 * counters["segments"]
 
     if rank == 0:
         photons_total = per_rank * world * args.steps
+        traffic = measured_traffic()
         gather_s = acc["gather_ms"] / 1e3
         achieved = bytes_model / gather_s / 1e9 if gather_s > 0 else 0.0
         pass_s = (acc["photon_trace_ms"] + acc["deposit_sort_ms"] + acc["gather_ms"]) / 1e3
@@ -152,10 +168,14 @@ def main():
                        "hitpoints": counters["hitpoints"]},
             "photon_pass_mphotons_per_s": per_rank * args.steps / pass_s / 1e6 if pass_s > 0 else None,
             "kernel_ms_per_step": {k: v / args.steps for k, v in acc.items()},
-            "counters_last_step": counters,
+            "counters_per_step": {k: (v / args.steps if k != "hitpoints" else v) for k, v in counters.items()},
             "roofline": {"kernel": "k_gather", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "bytes_model": "40*candidates + 32*accepted + 64*segments per launch",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
+                         "traffic_source": ("profiles/" + traffic[1] + ": (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc")
+                         if traffic else None,
+                         "bytes_model": "40*candidates + 32*accepted + 64*segments per launch (algorithmic bytes of the "
+                                        "reference's radius search + update loop; the cell-shared sweep re-uses them on chip)",
+                         "algorithmic_bytes_per_launch": bytes_model / max(1, gather_launches),
                          "avg_launch_ms": acc["gather_ms"] / max(1, gather_launches)},
         }
         if not args.no_cpu_baseline and world == 1:

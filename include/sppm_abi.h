@@ -197,6 +197,11 @@ int sppm_resolve_device(sppm_ctx* ctx, float* dev_pic_hw3);
 int sppm_synchronize(sppm_ctx* ctx);
 
 /* Copy out up to cap HitPoints; *n receives |Hvec|. */
+/* Counters and timings normally restart at every sppm_eye_pass.  accumulate = 1 clears them now and
+ * lets them run on over the following passes (a benchmark reads them once after K iterations instead
+ * of waiting for the stream after each); accumulate = 0 clears them and restores the default. */
+int sppm_stats_mode(sppm_ctx* ctx, int accumulate);
+
 int sppm_get_hitpoints(sppm_ctx* ctx, sppm_hitpoint* out, uint64_t cap, uint64_t* n);
 int sppm_get_counters(sppm_ctx* ctx, sppm_counters* out);
 int sppm_get_timings(sppm_ctx* ctx, sppm_timings* out);

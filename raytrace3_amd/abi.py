@@ -96,6 +96,7 @@ ABI_SYMBOLS = {
     "sppm_resolve": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
     "sppm_resolve_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sppm_synchronize": (C.c_int, [C.c_void_p]),
+    "sppm_stats_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "sppm_get_hitpoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "sppm_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "sppm_get_timings": (C.c_int, [C.c_void_p, C.POINTER(Timings)]),
@@ -186,6 +187,10 @@ class SppmContext:
     def synchronize(self):
         """Wait for the queued passes; raises if one of them overflowed a queue."""
         self._check(self.lib.sppm_synchronize(self._ctx), "sppm_synchronize")
+
+    def stats_mode(self, accumulate):
+        """accumulate=True: counters / timings run on over passes from now; False: restart at each eye pass."""
+        self._check(self.lib.sppm_stats_mode(self._ctx, 1 if accumulate else 0), "sppm_stats_mode")
 
     def resolve_device(self, dev_ptr):
         self._check(self.lib.sppm_resolve_device(self._ctx, C.c_void_p(dev_ptr)), "sppm_resolve_device")

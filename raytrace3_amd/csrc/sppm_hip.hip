@@ -31,6 +31,9 @@ using namespace sppm;
 struct __attribute__((aligned(32))) PosKey { double x, y, z; uint64_t key; };
 // bucket: grid bucket in bits 0..23, path vertex (bounce) in bits 24..31; photon: global photon index
 struct __attribute__((aligned(32))) DepB { float nx, ny, nz, fr, fg, fb; uint32_t bucket, photon; };
+// One deposit = one 64-byte record (position + cell key | normal, flux, bucket, photon): one scattered
+// write when it is sorted, four consecutive 16-byte loads per lane when a row of them is gathered.
+struct __attribute__((aligned(64))) Deposit { PosKey a; DepB b; };
 struct RawHit { double pos[3]; float n[3]; float v[3]; float wgt[3]; int pix, node, obj; };
 struct HpMeta { float v[3]; int node, obj, N; };
 // A parked ray: either one whose Bezier patch solves were deferred to k_newton (task_count > 0;
@@ -54,7 +57,7 @@ struct SceneParams {
 };
 
 struct DevCounters {
-    unsigned long long photons, segments, deposits, candidates, accepted, newton_calls, eye_segments, hits;
+    unsigned long long photons, segments, deposits, candidates, accepted, newton_calls, eye_segments;
     unsigned int overflow;   // bit0 hitpoint capacity, bit1 eye task queue, bit2 deposit capacity
     unsigned int pad;
 };
@@ -164,7 +167,11 @@ __device__ __forceinline__ unsigned long long chunk_alloc(bool want, unsigned lo
 }
 
 enum { MODE_EYE = 0, MODE_PHOTON = 1 };
-#define TRACE_WORK_CHUNK 128u     // work items a wave claims per atomic on the work counter
+#ifndef TRACE_WORK_CHUNK_EYE
+#define TRACE_WORK_CHUNK_EYE 128u
+#endif
+// work items a wave claims per atomic on the work counter
+#define TRACE_WORK_CHUNK (MODE == MODE_EYE ? TRACE_WORK_CHUNK_EYE : 128u)
 #define TRACE_SLOT_CHUNK 256u     // deposit slots a wave claims per atomic on the deposit counter
 #define DEP_HOLE 0x00ffffffu      // DepB::bucket of a claimed but unused slot (buckets are < 2^22)
 
@@ -182,10 +189,11 @@ struct TraceParams {
     // eye pass
     double pos[3], dir[3], du[3], dv[3];
     int w, h;
-    RawHit* hits; unsigned long long* n_hits; unsigned long long hit_cap;
+    RawHit* hits; unsigned long long* n_hits; unsigned long long hit_cap;   // n_hits: claimed slots
+    unsigned long long* n_real_hits;                                          // HitPoints written
     // photon pass
     const DevLight* lights; int n_lights; uint32_t per_round;
-    PosKey* depA; DepB* depB; unsigned long long* n_dep; unsigned long long dep_cap;
+    Deposit* dep; unsigned long long* n_dep; unsigned long long dep_cap;
     uint32_t* dcount; GridParams grid;
     unsigned long long* wave_chunks;          // per wave slot {next, end} of its open deposit-slot chunk
 };
@@ -457,7 +465,8 @@ __global__ void __launch_bounds__(256, COOP ? 2 : 3) k_trace(SceneParams sp, Tra
             if (dp) {
                 ndep++;
                 if (slot < tp.dep_cap) {
-                    tp.depA[slot] = da; tp.depB[slot] = db;
+                    Deposit rec; rec.a = da; rec.b = db;
+                    tp.dep[slot] = rec;
                     atomicAdd(&tp.dcount[db.bucket & 0xffffffu], 1u);
                 } else atomicOr(&tp.counters->overflow, 4u);
             }
@@ -470,7 +479,7 @@ __global__ void __launch_bounds__(256, COOP ? 2 : 3) k_trace(SceneParams sp, Tra
     flush_counter(&tp.counters->newton_calls, ncalls);
     if (MODE == MODE_EYE) {
         flush_counter(&tp.counters->eye_segments, nseg);
-        flush_counter(&tp.counters->hits, nhit);
+        flush_counter(tp.n_real_hits, nhit);
     } else {
         flush_counter(&tp.counters->segments, nseg);
         flush_counter(&tp.counters->deposits, ndep);
@@ -582,29 +591,28 @@ __global__ void k_hp_scatter(const RawHit* hits, uint32_t n, GridParams g, const
     hp_meta[s] = m;
 }
 
-__global__ void k_dep_scatter(const PosKey* depA, const DepB* depB, const unsigned long long* n_dep, unsigned long long cap,
-                              const uint32_t* start, uint32_t* cursor, PosKey* sA, DepB* sB) {
+__global__ void k_dep_scatter(const Deposit* __restrict__ dep, const unsigned long long* n_dep, unsigned long long cap,
+                              const uint32_t* __restrict__ start, uint32_t* cursor, Deposit* __restrict__ sorted) {
     unsigned long long n = min(*n_dep, cap);
     for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * blockDim.x) {
-        DepB b = depB[i];
-        const uint32_t bk = b.bucket & 0xffffffu;
+        const Deposit d = dep[i];
+        const uint32_t bk = d.b.bucket & 0xffffffu;
         if (bk == DEP_HOLE) continue;
-        uint32_t s = start[bk] + atomicAdd(&cursor[bk], 1u);
-        sA[s] = depA[i];
-        sB[s] = b;
+        const uint32_t s = start[bk] + atomicAdd(&cursor[bk], 1u);
+        sorted[s] = d;
     }
 }
 
 // Marks the unused tail of every wave slot's open chunk as holes (run once per eye pass / photon batch,
-// after the last trace launch, before the records are sorted).  Exactly one of depB / hits is set.
-__global__ void k_close_chunks(const unsigned long long* __restrict__ wave_chunks, uint32_t n_slots, DepB* depB, RawHit* hits, unsigned long long cap) {
+// after the last trace launch, before the records are sorted).  Exactly one of dep / hits is set.
+__global__ void k_close_chunks(const unsigned long long* __restrict__ wave_chunks, uint32_t n_slots, Deposit* dep, RawHit* hits, unsigned long long cap) {
     const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (w >= n_slots) return;
     const unsigned long long a = wave_chunks[2 * w], b = wave_chunks[2 * w + 1];
     for (unsigned long long h = a + lane_id(); h < b; h += 64)
         if (h < cap) {
-            if (depB) depB[h].bucket = DEP_HOLE;
+            if (dep) dep[h].b.bucket = DEP_HOLE;
             else hits[h].pix = -1;
         }
 }
@@ -642,8 +650,8 @@ __device__ __forceinline__ float wave_total_f(float v) {
 // One tile = 64 consecutive grid-sorted HitPoints, one per lane.
 __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
                                             const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, const uint32_t n_hp,
-                                            const uint32_t* __restrict__ dstart, const PosKey* __restrict__ dA,
-                                            const DepB* __restrict__ dB, const GridParams g, uint32_t& cand, uint32_t& acc_n) {
+                                            const uint32_t* __restrict__ dstart, const Deposit* __restrict__ deps,
+                                            const GridParams g, uint32_t& cand, uint32_t& acc_n) {
     const int lane = lane_id();
     const uint32_t mine = base + lane;
     const bool valid = (uint32_t)lane < GATHER_TILE && mine < n_hp;
@@ -698,8 +706,8 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
                     }
                     F += 64;
                     if (in) {
-                        const PosKey a = dA[src];
-                        const DepB b = dB[src];     // fetched with the position, not after the key check: one memory latency per row
+                        const PosKey a = deps[src].a;
+                        const DepB b = deps[src].b;   // fetched with the position, not after the key check: one memory latency per row
                         if (a.key == (((uint64_t)khi << 32) | klo)) {   // else: another cell hashed into this bucket
                             ax[r] = a.x; ay[r] = a.y; az[r] = a.z;
                             bnx[r] = b.nx; bny[r] = b.ny; bnz[r] = b.nz;
@@ -755,8 +763,8 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
 // other eighths when its own is drained (tile cost varies with the photon density around it).
 __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
                                                 const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
-                                                const uint32_t* __restrict__ dstart, const PosKey* __restrict__ dA,
-                                                const DepB* __restrict__ dB, GridParams g, uint32_t* tile_ctr, DevCounters* counters) {
+                                                const uint32_t* __restrict__ dstart, const Deposit* __restrict__ deps,
+                                                GridParams g, uint32_t* tile_ctr, DevCounters* counters) {
     const uint32_t n_tiles = (n_hp + GATHER_TILE - 1u) / GATHER_TILE;
     const uint32_t per = (n_tiles + 7u) >> 3;
     uint32_t cand = 0, acc_n = 0;   // wave-uniform tallies
@@ -768,7 +776,7 @@ __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_po
             if (lane_id() == 0) t = atomicAdd(&tile_ctr[q * 16], 1u);
             t = bcast_u(t, 0) + q * per;
             if (t >= q_end) break;
-            gather_tile(t * GATHER_TILE, hp_pos, hp_nr, hp_wgt, hp_tao, n_hp, dstart, dA, dB, g, cand, acc_n);
+            gather_tile(t * GATHER_TILE, hp_pos, hp_nr, hp_wgt, hp_tao, n_hp, dstart, deps, g, cand, acc_n);
         }
     }
     if (lane_id() == 0) {
@@ -889,6 +897,7 @@ struct sppm_ctx {
     bool photon_coop = true;
     int newton_blocks_per_cu = 8;
     int gather_blocks_per_cu = 4;
+    int scatter_blocks_per_cu = 32;
     bool verbose = false;
     DevBuf<uint32_t> bucket_of, hstart;
     DevBuf<uint32_t> hist;                // HitPoint histogram | scatter cursors | deposit histogram, (M + 1) words each
@@ -900,7 +909,7 @@ struct sppm_ctx {
     uint64_t n_hp = 0;
     GridParams grid{};
     // photon pass
-    DevBuf<PosKey> depA, sdepA; DevBuf<DepB> depB, sdepB;
+    DevBuf<Deposit> dep, sdep;   // deposits of a batch as traced / sorted by bucket
     DevBuf<uint32_t> dstart, scan_partial;
     // Control block, one allocation so that one memset resets a pass: queue scalars (CTL_SCALARS x u64) |
     // gather tile counters (8 x 16 u32, 64 B apart) | {next, end} of the open output chunk of every trace wave slot
@@ -910,6 +919,7 @@ struct sppm_ctx {
     unsigned long long* wave_chunks() const { return ctl.p + CTL_SCALARS + 64; }
     size_t ctl_words() const { return CTL_SCALARS + 64 + 2 * (size_t)num_cu * 4 * 4; }
     DevBuf<DevCounters> counters;
+    bool accumulate_stats = false;        // counters and timing spans run on over eye passes (sppm_stats_mode)
     bool check_pending = false;           // launches since the last look at the overflow flags
     DevBuf<float> pic;
     uint64_t last_rounds = 0, last_per_round = 0;
@@ -1001,6 +1011,7 @@ int sppm_create(sppm_ctx** out, int device_id) {
     if (const char* b = getenv("SPPM_FORCE_COOP")) ctx->force_coop = atoi(b) != 0;
     if (const char* b = getenv("SPPM_PHOTON_COOP")) ctx->photon_coop = atoi(b) != 0;
     if (const char* b = getenv("SPPM_GATHER_BPC")) ctx->gather_blocks_per_cu = std::max(1, atoi(b));
+    if (const char* b = getenv("SPPM_SCATTER_BPC")) ctx->scatter_blocks_per_cu = std::max(1, atoi(b));
     if (const char* b = getenv("SPPM_NEWTON_BPC")) ctx->newton_blocks_per_cu = std::max(1, atoi(b));
     if (const char* b = getenv("SPPM_VERBOSE")) ctx->verbose = atoi(b) != 0;
     if (ctx->ctl.reserve(ctx->ctl_words()) != hipSuccess || ctx->counters.reserve(1) != hipSuccess) {
@@ -1022,7 +1033,7 @@ void sppm_destroy(sppm_ctx* ctx) {
     ctx->raw.release(); ctx->park[0].release(); ctx->park[1].release(); ctx->ntask[0].release(); ctx->ntask[1].release(); ctx->nres.release();
     ctx->bucket_of.release(); ctx->hist.release(); ctx->hstart.release();
     ctx->hp_pos.release(); ctx->hp_nr.release(); ctx->hp_wgt.release(); ctx->hp_tao.release(); ctx->hp_meta.release();
-    ctx->depA.release(); ctx->sdepA.release(); ctx->depB.release(); ctx->sdepB.release();
+    ctx->dep.release(); ctx->sdep.release();
     ctx->dstart.release(); ctx->scan_partial.release(); ctx->ctl.release(); ctx->counters.release(); ctx->pic.release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1159,7 +1170,7 @@ static int launch_scan(sppm_ctx* ctx, const uint32_t* cnt, uint32_t* start, uint
 }  // extern "C" (templates below need C++ linkage)
 
 // queue scalars of the control block
-enum { SC_HITS = 0, SC_DEP = 1, SC_NEXT0 = 2 /* .. SC_NEXT0 + 3 */, SC_PARK0 = 6, SC_TASK0 = 7, SC_PARK1 = 8, SC_TASK1 = 9 };
+enum { SC_HITS = 0, SC_DEP = 1, SC_NEXT0 = 2 /* .. SC_NEXT0 + 3 */, SC_PARK0 = 6, SC_TASK0 = 7, SC_PARK1 = 8, SC_TASK1 = 9, SC_REAL_HITS = 10 };
 
 static int trace_max_blocks(const sppm_ctx* ctx) { return ctx->num_cu * 4; }
 // output slots that can be left unused in open chunks (one chunk per wave slot of the largest trace grid)
@@ -1170,9 +1181,9 @@ static int reset_ctl(sppm_ctx* ctx) {
     return SPPM_OK;
 }
 // Turns the unused tails of the open chunks into holes once the trace launches of a batch / pass are done.
-static int close_chunks(sppm_ctx* ctx, DepB* depB, RawHit* hits, uint64_t cap) {
+static int close_chunks(sppm_ctx* ctx, Deposit* dep, RawHit* hits, uint64_t cap) {
     const uint32_t n_slots = (uint32_t)trace_max_blocks(ctx) * 4u;
-    hipLaunchKernelGGL(k_close_chunks, dim3((n_slots + 3) / 4), dim3(256), 0, ctx->stream, ctx->wave_chunks(), n_slots, depB, hits,
+    hipLaunchKernelGGL(k_close_chunks, dim3((n_slots + 3) / 4), dim3(256), 0, ctx->stream, ctx->wave_chunks(), n_slots, dep, hits,
                        (unsigned long long)cap);
     HIPCHK(hipGetLastError());
     return SPPM_OK;
@@ -1305,18 +1316,19 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
     ctx->have_eye = false;
     const uint64_t npx = (uint64_t)cam->w * cam->h;
     uint64_t hit_cap = std::max<uint64_t>(2 * npx, 1 << 16) + dep_slack(ctx);
-    drop_spans(ctx);
+    if (!ctx->accumulate_stats) drop_spans(ctx);
     QueueState q{};
     for (int attempt = 0;; attempt++) {
         HIPCHK(ctx->raw.reserve(hit_cap));
         // the tallies restart; the overflow flags stay until the host has looked at them
-        HIPCHK(hipMemsetAsync(ctx->counters.p, 0, offsetof(DevCounters, overflow), ctx->stream));
+        if (!ctx->accumulate_stats) HIPCHK(hipMemsetAsync(ctx->counters.p, 0, offsetof(DevCounters, overflow), ctx->stream));
         if (int rc = reset_ctl(ctx)) return rc;
         tic(ctx, PH_EYE);
         TraceParams tp{};
         for (int k = 0; k < 3; k++) { tp.pos[k] = cam->pos[k]; tp.dir[k] = cam->dir[k]; tp.du[k] = cam->du[k]; tp.dv[k] = cam->dv[k]; }
         tp.w = cam->w; tp.h = cam->h;
         tp.hits = ctx->raw.p; tp.n_hits = ctx->scalars() + SC_HITS; tp.hit_cap = hit_cap;
+        tp.n_real_hits = ctx->scalars() + SC_REAL_HITS;
         tp.counters = ctx->counters.p;
         tp.wave_chunks = ctx->wave_chunks();
         tp.rng = host_rng_base(seed, replica * 4u + D_EYE);
@@ -1327,11 +1339,11 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
         if (rc != SPPM_RETRY_HITS) return rc;
         if (attempt == 5) return fail(ctx, SPPM_E_CAPACITY, "HitPoint buffer overflowed after 5 capacity doublings");
         hit_cap *= 2;
-        drop_spans(ctx);
+        if (!ctx->accumulate_stats) drop_spans(ctx);
     }
     // q is the state after the last launch: claimed slots of the raw array (with holes) and the HitPoints in them
     const unsigned long long claimed = std::min<unsigned long long>(q.sc[SC_HITS], hit_cap);
-    ctx->n_hp = q.dc.hits;
+    ctx->n_hp = q.sc[SC_REAL_HITS];
     // ---- hashed grid over HitPoints
     const uint64_t n = ctx->n_hp;
     const double cs = std::sqrt(SPPM_INIT_R2) * 1.0001;   // cell >= search radius: neighbours within +-1 cell
@@ -1365,7 +1377,7 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
 static void fill_photon_params(sppm_ctx* ctx, TraceParams& tp, uint32_t per_round, uint64_t dep_cap, uint64_t seed, uint32_t replica,
                                DevCounters* counters) {
     tp.lights = ctx->lights.p; tp.n_lights = ctx->n_lights; tp.per_round = per_round;
-    tp.depA = ctx->depA.p; tp.depB = ctx->depB.p; tp.n_dep = ctx->scalars() + SC_DEP; tp.dep_cap = dep_cap;
+    tp.dep = ctx->dep.p; tp.n_dep = ctx->scalars() + SC_DEP; tp.dep_cap = dep_cap;
     tp.dcount = ctx->dcount(); tp.grid = ctx->grid; tp.counters = counters;
     tp.wave_chunks = ctx->wave_chunks();
     tp.rng = host_rng_base(seed, replica * 4u + D_PHOTON);
@@ -1379,6 +1391,15 @@ static int check_deferred(sppm_ctx* ctx) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->check_pending = false;
     if (overflow_code(ctx, dc) != SPPM_OK) return fail(ctx, SPPM_E_CAPACITY, "a ray / task / deposit queue overflowed in an earlier pass");
+    return SPPM_OK;
+}
+
+int sppm_stats_mode(sppm_ctx* ctx, int accumulate) {
+    if (!ctx) return SPPM_E_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->accumulate_stats = accumulate != 0;
+    drop_spans(ctx);
+    HIPCHK(hipMemsetAsync(ctx->counters.p, 0, offsetof(DevCounters, overflow), ctx->stream));
     return SPPM_OK;
 }
 
@@ -1404,8 +1425,7 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
     const uint32_t M = ctx->grid.mask + 1;
     const uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(ctx->batch, end > photon_begin ? end - photon_begin : 1));
     const uint64_t dep_cap = batch * (SPPM_MAX_DEP + 1) + dep_slack(ctx);
-    HIPCHK(ctx->depA.reserve(dep_cap)); HIPCHK(ctx->depB.reserve(dep_cap));
-    HIPCHK(ctx->sdepA.reserve(dep_cap)); HIPCHK(ctx->sdepB.reserve(dep_cap));
+    HIPCHK(ctx->dep.reserve(dep_cap)); HIPCHK(ctx->sdep.reserve(dep_cap));
     TraceParams tp{};
     fill_photon_params(ctx, tp, per_round, dep_cap, seed, replica, ctx->counters.p);
     QueueState q{};
@@ -1416,12 +1436,12 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
         tic(ctx, PH_TRACE);
         bool synced = false;
         if (int rc = run_trace(ctx, MODE_PHOTON, tp, first, count, false, false, q, &synced)) return rc;
-        if (int rc = close_chunks(ctx, ctx->depB.p, nullptr, dep_cap)) return rc;
+        if (int rc = close_chunks(ctx, ctx->dep.p, nullptr, dep_cap)) return rc;
         toc(ctx);
         tic(ctx, PH_SORT);
         if (int rc = launch_scan(ctx, ctx->dcount(), ctx->dstart.p, M)) return rc;
-        hipLaunchKernelGGL(k_dep_scatter, dim3(ctx->num_cu * 8), dim3(256), 0, ctx->stream, ctx->depA.p, ctx->depB.p, ctx->scalars() + SC_DEP,
-                           dep_cap, ctx->dstart.p, ctx->cursor(), ctx->sdepA.p, ctx->sdepB.p);
+        hipLaunchKernelGGL(k_dep_scatter, dim3(ctx->num_cu * ctx->scatter_blocks_per_cu), dim3(256), 0, ctx->stream, ctx->dep.p, ctx->scalars() + SC_DEP,
+                           dep_cap, ctx->dstart.p, ctx->cursor(), ctx->sdep.p);
         HIPCHK(hipGetLastError());
         toc(ctx);
         if (ctx->n_hp > 0) {
@@ -1429,7 +1449,7 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
             const uint64_t tiles = (ctx->n_hp + GATHER_TILE - 1) / GATHER_TILE;
             const int blocks = (int)std::max<uint64_t>(8, std::min<uint64_t>((uint64_t)ctx->num_cu * ctx->gather_blocks_per_cu, ((tiles + 3) / 4 + 7) / 8 * 8));
             hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->hp_tao.p,
-                               (uint32_t)ctx->n_hp, ctx->dstart.p, ctx->sdepA.p, ctx->sdepB.p, ctx->grid, ctx->tile_ctr(), ctx->counters.p);
+                               (uint32_t)ctx->n_hp, ctx->dstart.p, ctx->sdep.p, ctx->grid, ctx->tile_ctr(), ctx->counters.p);
             HIPCHK(hipGetLastError());
             toc(ctx);
             ctx->gather_launches++;
@@ -1565,8 +1585,7 @@ int sppm_debug_photon_deposits(sppm_ctx* ctx, uint64_t rounds, uint32_t per_roun
     if (count > (1u << 22)) return fail(ctx, SPPM_E_INVALID, "at most 2^22 photons per debug call");
     HIPCHK(hipSetDevice(ctx->device));
     const uint64_t dep_cap = count * (SPPM_MAX_DEP + 1) + dep_slack(ctx);
-    HIPCHK(ctx->depA.reserve(dep_cap)); HIPCHK(ctx->depB.reserve(dep_cap));
-    HIPCHK(ctx->sdepA.reserve(dep_cap)); HIPCHK(ctx->sdepB.reserve(dep_cap));
+    HIPCHK(ctx->dep.reserve(dep_cap)); HIPCHK(ctx->sdep.reserve(dep_cap));
     if (int rc = check_deferred(ctx)) return rc;
     DevBuf<DevCounters> scratch_counters;   // keep the pass counters untouched
     HIPCHK(scratch_counters.reserve(1));
@@ -1582,7 +1601,7 @@ int sppm_debug_photon_deposits(sppm_ctx* ctx, uint64_t rounds, uint32_t per_roun
     bool synced = false;
     if (rrc == SPPM_OK) rrc = run_trace(ctx, MODE_PHOTON, tp, photon_begin, count, false, true, q, &synced);
     ctx->counters.p = saved;
-    if (rrc == SPPM_OK) rrc = close_chunks(ctx, ctx->depB.p, nullptr, dep_cap);
+    if (rrc == SPPM_OK) rrc = close_chunks(ctx, ctx->dep.p, nullptr, dep_cap);
     unsigned long long nd = 0;
     hipError_t e = hipMemcpyAsync(&nd, ctx->scalars() + SC_DEP, sizeof(nd), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1594,17 +1613,18 @@ int sppm_debug_photon_deposits(sppm_ctx* ctx, uint64_t rounds, uint32_t per_roun
     const uint64_t claimed = std::min<uint64_t>(nd, dep_cap);
     uint64_t real = 0;
     if (claimed) {
-        std::vector<PosKey> a(claimed); std::vector<DepB> b(claimed);
-        HIPCHK(hipMemcpy(a.data(), ctx->depA.p, claimed * sizeof(PosKey), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(b.data(), ctx->depB.p, claimed * sizeof(DepB), hipMemcpyDeviceToHost));
+        std::vector<Deposit> recs(claimed);
+        HIPCHK(hipMemcpy(recs.data(), ctx->dep.p, claimed * sizeof(Deposit), hipMemcpyDeviceToHost));
         for (uint64_t i = 0; i < claimed; i++) {
-            if ((b[i].bucket & 0xffffffu) == DEP_HOLE) continue;
+            const PosKey& a = recs[i].a;
+            const DepB& b = recs[i].b;
+            if ((b.bucket & 0xffffffu) == DEP_HOLE) continue;
             if (real < cap) {
                 double* o = out + 11 * real;
-                o[0] = (double)b[i].photon; o[1] = (double)(b[i].bucket >> 24);
-                o[2] = a[i].x; o[3] = a[i].y; o[4] = a[i].z;
-                o[5] = b[i].nx; o[6] = b[i].ny; o[7] = b[i].nz;
-                o[8] = b[i].fr; o[9] = b[i].fg; o[10] = b[i].fb;
+                o[0] = (double)b.photon; o[1] = (double)(b.bucket >> 24);
+                o[2] = a.x; o[3] = a.y; o[4] = a.z;
+                o[5] = b.nx; o[6] = b.ny; o[7] = b.nz;
+                o[8] = b.fr; o[9] = b.fg; o[10] = b.fb;
             }
             real++;
         }
