@@ -551,7 +551,7 @@ struct oracle_ctx {
     // ---- Raytracer.h:296-357 ViewTrace (recursive tree)
     void ViewTrace(const V3& org, const V3& dir, int dep, V3 wgt, int x, int y, uint32_t node,
                    uint64_t seed, uint32_t replica) {
-        cnt.eye_segments++;
+        if (dep <= MAX_DEP_) cnt.eye_segments++;   // like `segments`: the call whose result the depth test discards is not tallied
         Rand rnd = make_rand(seed, replica, D_EYE, (uint32_t)(x * cam.w + y), node);
         Collision c1 = NearCollide(org, dir, rnd);
         if (!c1.IsValid()) return;

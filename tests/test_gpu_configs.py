@@ -1,0 +1,274 @@
+"""GPU parity at the benchmark configurations and on the material / light / depth edge cases.
+
+Each configuration of BASELINE.json is checked twice:
+  * against the CPU oracle on the same seeded inputs, at a size the oracle finishes in seconds
+    (the full 800x600 eye pass of config 2 included; photon passes on a slice of the photon range,
+    which the counter RNG makes identical to the same slice of the full pass);
+  * at its full size on the GPU alone through properties that do not need the oracle: the photon
+    count, sum(newN) == accepted updates, additivity over photon shards (what multi-GPU sharding
+    relies on) and independence of the batch size.
+Tolerances are those of tests/test_gpu_parity.py (flux image relative to its mean: |diff| <= 1e-3 on
+>= 99.5 % of pixels, analytic scenes; 97 % where Bezier Newton results differ at the fp32 scale).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from raytrace3_amd import SppmContext, scenes
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20260101
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    ctx = SppmContext(0)
+    yield ctx
+    ctx.close()
+
+
+def _oracle(scene):
+    o = ol.OracleContext()
+    o.set_scene(scene)
+    return o
+
+
+def _key(hp):
+    return (hp["x"].astype(np.int64) << 40) | (hp["y"].astype(np.int64) << 20) | hp["node"].astype(np.int64)
+
+
+def _match(g, c):
+    """HitPoints of both sides restricted to the (pixel, tree node) keys they share, in the same order."""
+    kg, kc = _key(g), _key(c)
+    common, ig, ic = np.intersect1d(kg, kc, return_indices=True)
+    return g[ig], c[ic], len(common)
+
+
+def _analytic_positions(g, c):
+    """Plane / sphere HitPoints, fp64 on both sides.  Seen directly (tree node 0) they agree to 1e-9; behind a
+    mirror or glass sphere the last-bit differences of the two arithmetics (FMA contraction on the GPU) are
+    magnified by the curved surface (distance / radius per bounce) and by the distance travelled: 1e-10
+    relative + 1e-7 absolute (measured worst case 4.5e-8 at z = 1482 behind the mirror ball)."""
+    direct = c["node"] == 0
+    assert np.allclose(g["pos"][direct], c["pos"][direct], rtol=1e-12, atol=1e-9)
+    assert np.allclose(g["pos"][~direct], c["pos"][~direct], rtol=1e-10, atol=1e-7)
+
+
+def _image_parity(g, c, frac, linf=1e-3, mae=1e-4):
+    mean = c.mean()
+    assert mean > 0
+    diff = np.abs(g - c).max(axis=2) / mean
+    good = (diff <= linf).mean()
+    print(f"image parity: within {linf:g}: {good:.5f}, MAE/mean {diff.mean():.3g}, max {diff.max():.3g}")
+    assert good >= frac, good
+    assert diff.mean() <= mae, diff.mean()
+
+
+def _run_pair(gpu, scene, cam, rounds, per_round, count):
+    gpu.set_scene(scene)
+    gpu.eye_pass(cam, SEED)
+    gpu.photon_pass(rounds, per_round, SEED, photon_begin=0, photon_count=count)
+    o = _oracle(scene)
+    o.eye_pass(cam, SEED)
+    o.photon_pass(rounds, per_round, SEED, photon_begin=0, photon_count=count)
+    return o
+
+
+def _gpu_properties(gpu, rounds, per_round, n_lights=1, halves=True):
+    """Oracle-free checks of the photon pass just run on `gpu` (eye pass already done by the caller)."""
+    total = rounds * per_round * n_lights
+    gpu.photon_pass(rounds, per_round, SEED)
+    c = gpu.counters()
+    hp = gpu.hitpoints()
+    full = gpu.resolve()
+    assert c["photons"] == total
+    assert c["deposits"] <= c["segments"] <= 14 * total
+    assert int(hp["newN"].sum()) == c["accepted"] <= c["candidates"]
+    assert np.isfinite(full).all() and full.min() >= 0 and full.sum() > 0
+    if halves:
+        cut = (total // 2 // 64) * 64 + 17        # an uneven split, not on a batch boundary
+        acc = np.zeros_like(full)
+        for begin, count in ((0, cut), (cut, total - cut)):
+            gpu.eye_pass(gpu.cam, SEED)
+            gpu.photon_pass(rounds, per_round, SEED, photon_begin=begin, photon_count=count)
+            gpu.resolve(accumulate_into=acc)
+        # the same deposits, summed in another order in fp32
+        assert np.allclose(acc, full, rtol=2e-4, atol=1e-6 * full.mean())
+    return full, c
+
+
+# ------------------------------------------------------------------ config 1: spheres + plane, 256 x 256, 100 k photons
+def test_c1_full_size_against_oracle(gpu):
+    factory, (w, h), rounds, per_round = scenes.CONFIGS["c1_spheres_plane_256"]
+    scene, cam = factory(), scenes.default_camera(w, h)
+    o = _run_pair(gpu, scene, cam, rounds, per_round, 0)         # the whole pass: this is the reference's CPU-sized case
+    g, c = gpu.hitpoints(), o.hitpoints()
+    assert np.array_equal(np.sort(_key(g)), np.sort(_key(c)))
+    gm, cm, _ = _match(g, c)
+    _analytic_positions(gm, cm)
+    cg, co = gpu.counters(), o.counters()
+    assert cg["photons"] == co["photons"] == rounds * per_round
+    for k in ("segments", "deposits", "candidates", "accepted"):
+        assert cg[k] == pytest.approx(co[k], rel=1e-3), k
+    _image_parity(gpu.resolve(), o.resolve(), frac=0.995)
+
+
+# ------------------------------------------------------------------ config 2: teapot scene, 800 x 600, 1 M photons
+def test_c2_full_size_eye_pass_and_photon_slice_against_oracle(gpu):
+    factory, (w, h), rounds, per_round = scenes.CONFIGS["c2_teapot_800x600"]
+    scene, cam = factory(), scenes.default_camera(w, h)
+    o = _run_pair(gpu, scene, cam, rounds, per_round, 50_000)
+    g, c = gpu.hitpoints(), o.hitpoints()
+    gm, cm, n_common = _match(g, c)
+    # Bezier silhouettes: a Newton solve that converges in one arithmetic and not in the other moves a HitPoint
+    assert n_common >= 0.999 * len(c) and abs(len(g) - len(c)) <= 1e-3 * len(c), (len(g), len(c), n_common)
+    same = gm["obj"] == cm["obj"]
+    assert same.mean() >= 0.999
+    perr = np.abs(gm["pos"] - cm["pos"]).max(axis=1)[same]
+    analytic = cm["obj"][same] != 8
+    _analytic_positions(gm[same][analytic], cm[same][analytic])
+    assert (perr[~analytic] <= 1e-3).mean() >= 0.97
+    assert gpu.counters()["eye_segments"] == pytest.approx(o.counters()["eye_segments"], rel=1e-4)
+    _image_parity(gpu.resolve(), o.resolve(), frac=0.97, mae=2e-3)
+
+
+def test_c2_full_size_properties(gpu):
+    factory, (w, h), rounds, per_round = scenes.CONFIGS["c2_teapot_800x600"]
+    gpu.set_scene(factory())
+    gpu.eye_pass(scenes.default_camera(w, h), SEED)
+    assert 0.99 * w * h <= len(gpu.hitpoints()) <= w * h
+    _gpu_properties(gpu, rounds, per_round)
+
+
+# ------------------------------------------------------------------ config 4: four teapots (128 patches), 1920 x 1080
+def test_c4_reduced_against_oracle(gpu):
+    scene, cam = scenes.scene_teapot(4), scenes.default_camera(480, 270)
+    o = _run_pair(gpu, scene, cam, 10000, 100, 20_000)
+    g, c = gpu.hitpoints(), o.hitpoints()
+    gm, cm, n_common = _match(g, c)
+    assert n_common >= 0.995 * len(c)
+    same = gm["obj"] == cm["obj"]
+    assert same.mean() >= 0.995
+    perr = np.abs(gm["pos"] - cm["pos"]).max(axis=1)[same]
+    assert (perr <= 1e-3).mean() >= 0.97
+    assert gpu.counters()["newton_calls"] == pytest.approx(o.counters()["newton_calls"], rel=0.02)
+    _image_parity(gpu.resolve(), o.resolve(), frac=0.95, mae=4e-3)
+
+
+def test_c4_full_size_properties(gpu):
+    factory, (w, h), rounds, per_round = scenes.CONFIGS["c4_teapot4_1080p"]
+    gpu.set_scene(factory())
+    gpu.eye_pass(scenes.default_camera(w, h), SEED)
+    n = len(gpu.hitpoints())
+    assert 0.99 * w * h <= n <= w * h
+    _gpu_properties(gpu, rounds, per_round)
+
+
+# ------------------------------------------------------------------ config 5: glass ball caustic, 1024 x 1024, 50 M photons
+def test_c5_reduced_against_oracle(gpu):
+    scene, cam = scenes.scene_caustic(), scenes.default_camera(256, 256)
+    o = _run_pair(gpu, scene, cam, 500000, 100, 200_000)
+    g, c = gpu.hitpoints(), o.hitpoints()
+    assert np.array_equal(np.sort(_key(g)), np.sort(_key(c)))
+    cg, co = gpu.counters(), o.counters()
+    for k in ("segments", "deposits", "candidates", "accepted"):
+        assert cg[k] == pytest.approx(co[k], rel=1e-3), k
+    _image_parity(gpu.resolve(), o.resolve(), frac=0.995)
+
+
+def test_c5_full_size_many_batches(gpu):
+    factory, (w, h), rounds, per_round = scenes.CONFIGS["c5_caustic_1024"]
+    gpu.set_scene(factory())
+    gpu.eye_pass(scenes.default_camera(w, h), SEED)
+    full, c = _gpu_properties(gpu, rounds, per_round, halves=True)        # 50 M photons = 48 batches of 2^20
+    # the caustic: the brightest pixels sit under the glass ball, far above the mean of the lit floor
+    assert full.max() > 5 * full[full > 0].mean()
+
+
+def test_batch_size_is_immaterial(gpu):
+    """The same pass cut into batches of 3000 photons by a second context (SPPM_BATCH)."""
+    scene, cam = scenes.scene_spheres_plane(True), scenes.default_camera(64, 48)
+    gpu.set_scene(scene)
+    gpu.eye_pass(cam, SEED)
+    gpu.photon_pass(300, 100, SEED)
+    ref = gpu.resolve()
+    os.environ["SPPM_BATCH"] = "3000"
+    try:
+        small = SppmContext(0)
+    finally:
+        del os.environ["SPPM_BATCH"]
+    small.set_scene(scene)
+    small.eye_pass(cam, SEED)
+    small.photon_pass(300, 100, SEED)
+    assert small.timings()["gather_launches"] == 10
+    assert np.allclose(small.resolve(), ref, rtol=2e-4, atol=1e-6 * ref.mean())
+    assert small.counters() == gpu.counters()
+    small.close()
+
+
+# ------------------------------------------------------------------ materials, lights, depth
+def _materials_scene():
+    """Floor + back mirror + three spheres: glass that also reflects (eye paths branch, Raytracer.h:320-336),
+    MIRROR2 (a HitPoint and a reflection at every hit, Scene.h:108) and plain diffuse."""
+    s = scenes.FlatScene()
+    s.add_plane((50, 0, 81.6), (0, -1, 0), (.75, .75, .75), scenes.WHITE_DIFF)
+    s.add_plane((50, 40.8, 0), (0, 0, 1), (.75, .75, .75), scenes.MIRROR)
+    both = scenes.material(refl=(.3, .3, .3), refr=(.6, .6, .6), refrn=1.5)
+    s.add_sphere(14, (30, 14, 70), (.999, .999, .999), both)
+    s.add_sphere(12, (70, 12, 90), (.9, .9, .9), scenes.MIRROR2)
+    s.add_sphere(8, (50, 8, 120), (.9, .5, .5), scenes.WHITE_DIFF)
+    s.add_light((50, 60, 85), (5000, 5000, 5000))
+    return s
+
+
+def test_branching_eye_paths_and_two_lobe_materials(gpu):
+    scene, cam = _materials_scene(), scenes.default_camera(96, 72)
+    o = _run_pair(gpu, scene, cam, 300, 100, 0)
+    g, c = gpu.hitpoints(), o.hitpoints()
+    pixels = np.unique(c["x"].astype(np.int64) * 4096 + c["y"])
+    assert len(c) > 1.05 * len(pixels)                          # more HitPoints than lit pixels: the tree branched
+    assert (c["node"] > 2).any()
+    assert np.array_equal(np.sort(_key(g)), np.sort(_key(c)))   # same (pixel, tree node) set
+    gm, cm, _ = _match(g, c)
+    assert np.array_equal(gm["obj"], cm["obj"])
+    _analytic_positions(gm, cm)
+    assert np.allclose(gm["wgt"], cm["wgt"], rtol=2e-5, atol=1e-7)
+    assert gpu.counters()["eye_segments"] == o.counters()["eye_segments"]
+    cg, co = gpu.counters(), o.counters()
+    for k in ("segments", "deposits", "accepted"):
+        assert cg[k] == pytest.approx(co[k], rel=2e-3), k
+    _image_parity(gpu.resolve(), o.resolve(), frac=0.995)
+
+
+def test_two_lights_share_the_per_light_normaliser(gpu):
+    """Raytracer.h:288-293: the resolve divides by cnt * onetime, photons per LIGHT (two lights: twice the flux)."""
+    scene = scenes.scene_spheres_plane(True)
+    scene.add_light((20, 50, 120), (2500, 2500, 5000))
+    cam = scenes.default_camera(64, 64)
+    o = _run_pair(gpu, scene, cam, 100, 100, 0)
+    assert gpu.counters()["photons"] == o.counters()["photons"] == 2 * 100 * 100
+    _image_parity(gpu.resolve(), o.resolve(), frac=0.995)
+
+
+def test_paths_stop_at_the_depth_limit(gpu):
+    """Two facing mirrors: every path runs into MAX_DEP = 13 (Raytracer.h:126-133, :303-310): 14 hits traced."""
+    s = scenes.FlatScene()
+    s.add_plane((50, 40.8, 0), (0, 0, 1), (.9, .9, .9), scenes.MIRROR)
+    s.add_plane((50, 40.8, 300), (0, 0, 1), (.9, .9, .9), scenes.MIRROR)
+    s.add_plane((50, 0, 81.6), (0, -1, 0), (.75, .75, .75), scenes.WHITE_DIFF)
+    s.add_light((50, 60, 85), (5000, 5000, 5000))
+    cam = scenes.default_camera(32, 32)
+    o = _run_pair(gpu, s, cam, 50, 100, 0)
+    cg, co = gpu.counters(), o.counters()
+    assert cg["eye_segments"] == co["eye_segments"]
+    assert cg["segments"] == co["segments"]
+    assert cg["deposits"] == co["deposits"]
+    g, c = gpu.hitpoints(), o.hitpoints()
+    assert np.array_equal(np.sort(_key(g)), np.sort(_key(c)))
+    if c.size:
+        _image_parity(gpu.resolve(), o.resolve(), frac=0.995)
+    # a mirror-only eye path: 14 segments and no HitPoint
+    assert co["eye_segments"] >= 14
