@@ -154,31 +154,22 @@ __device__ __forceinline__ d3 rotated(d3 v, d3 a, double angle) {               
           v.z * (a.z * a.z + (1 - a.z * a.z) * cost);
     return r;
 }
-// Rodrigues rotation with the angle given by its cosine and sine (the body of Vec3::rotated, Vec3.h:102-114).
-__device__ __forceinline__ d3 rotated_cs(d3 v, d3 a, double cost, double sint) {
-    d3 r;
-    r.x = v.x * (a.x * a.x + (1 - a.x * a.x) * cost) + v.y * (a.x * a.y * (1 - cost) - a.z * sint) +
-          v.z * (a.x * a.z * (1 - cost) + a.y * sint);
-    r.y = v.x * (a.y * a.x * (1 - cost) + a.z * sint) + v.y * (a.y * a.y + (1 - a.y * a.y) * cost) +
-          v.z * (a.y * a.z * (1 - cost) - a.x * sint);
-    r.z = v.x * (a.z * a.x * (1 - cost) - a.y * sint) + v.y * (a.z * a.y * (1 - cost) + a.x * sint) +
-          v.z * (a.z * a.z + (1 - a.z * a.z) * cost);
-    return r;
-}
-// Vec3::GetUnitRandRefl, Vec3.h:90-98.  theta = acos(sqrt(u1)), so cos(theta) = sqrt(u1) and
-// sin(theta) = sqrt(1 - u1): the two square roots replace acos + cos + sin (equal to rounding).  The
-// |angle| < 1e-4 early return of Vec3::rotated needs theta < 1e-4, i.e. u1 > 1 - 1e-8, which a 24-bit
-// uniform never reaches; for phi it is kept.
+// Vec3::GetUnitRandRefl, Vec3.h:90-98: rotate n about a = GetAnormal(n) by theta = acos(sqrt(u1)), the
+// result about n by phi = 2 PI u2, normalise.  With a perpendicular to n and both of unit length the two
+// Rodrigues rotations (Vec3::rotated, Vec3.h:99-115) collapse to
+//     n cos(theta) + sin(theta) (b cos(phi) + a sin(phi)),   b = a x n,
+// and cos(theta) = sqrt(u1), sin(theta) = sqrt(1 - u1): the same direction as the reference's matrix
+// form up to fp64 rounding, for ~1/4 of its operations and without acos.  Vec3::rotated returns its input
+// when |angle| < 1e-4: for theta that needs u1 > 1 - 1e-8, which a 24-bit uniform never reaches; for phi
+// the early return is kept (cos = 1, sin = 0).
 __device__ __forceinline__ d3 rand_refl(d3 n, double u1, double u2) {
     const double cost = sqrt(u1), sint = sqrt(1.0 - u1);
     const double phi = 2 * SPPM_PI * u2;
-    d3 ret = rotated_cs(n, get_anormal(n), cost, sint);
-    if (!(fabs(phi) < SPPM_EPS)) {
-        double sp, cp;
-        sincos(phi, &sp, &cp);
-        ret = rotated_cs(ret, n, cp, sp);
-    }
-    return get_unit(ret);
+    double sp = 0.0, cp = 1.0;
+    if (!(fabs(phi) < SPPM_EPS)) sincos(phi, &sp, &cp);
+    const d3 a = get_anormal(n);
+    const d3 b = cross(a, n);
+    return get_unit(n * cost + (b * cp + a * sp) * sint);
 }
 __device__ __forceinline__ d3 refracted(d3 I, d3 N, double n) {                            // Vec3.h:124-134
     double cosI = -dot(N, I);

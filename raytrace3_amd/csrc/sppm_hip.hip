@@ -166,6 +166,9 @@ __device__ __forceinline__ unsigned long long chunk_alloc(bool want, unsigned lo
     return slot;
 }
 
+#ifndef TRACE_COOP_OCC
+#define TRACE_COOP_OCC 2
+#endif
 enum { MODE_EYE = 0, MODE_PHOTON = 1 };
 #ifndef TRACE_WORK_CHUNK_EYE
 #define TRACE_WORK_CHUNK_EYE 128u
@@ -208,7 +211,7 @@ struct TraceParams {
 // k_newton solves all tasks of the round at full occupancy, and the next launch resumes the ray
 // from its record.  This keeps the 50 x 10 Newton iterations out of the divergent path loop.
 template <int MODE, bool COOP>
-__global__ void __launch_bounds__(256, COOP ? 2 : 3) k_trace(SceneParams sp, TraceParams tp) {
+__global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneParams sp, TraceParams tp) {
     const unsigned long long n_resume = tp.resume ? *tp.n_resume_dev : 0ull;
     const unsigned long long total = n_resume + tp.fresh_count;
     // the host sizes a resume launch without knowing its count: workgroups beyond the work leave at once
@@ -923,7 +926,7 @@ struct sppm_ctx {
     bool check_pending = false;           // launches since the last look at the overflow flags
     DevBuf<float> pic;
     uint64_t last_rounds = 0, last_per_round = 0;
-    uint64_t batch = 1u << 20;
+    uint64_t batch = 1u << 22;            // photons traced, sorted and gathered together (128 B of deposit buffers per photon x 14)
     // HIP-event spans on the stream, read back (and only then waited for) by sppm_get_timings
     struct Span { int phase; hipEvent_t a, b; };
     std::vector<hipEvent_t> ev_pool;
