@@ -229,6 +229,9 @@ __global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneP
     // Work items and deposit slots are claimed from the global counters a chunk at a time (all waves
     // hammering one address with a returned atomic per loop iteration serialises the whole grid).
     unsigned long long work_next = 0, work_end = 0;     // this wave's claimed work items, wave-uniform
+    unsigned long long chunk_base = 0;                  // first item of the chunk the emission directions in LDS belong to
+    // per-wave LDS slice behind the scene tables: emission directions of the claimed photon chunk
+    double* emit_dir = (double*)((char*)lds_scene + ((sp.blob_bytes + 15) & ~15)) + (threadIdx.x >> 6) * (3 * 128);
     unsigned long long slot_next = 0, slot_end = 0;     // this wave's open chunk of output slots (deposits / raw HitPoints), wave-uniform
     const uint32_t wave_slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     slot_next = tp.wave_chunks[2 * wave_slot];
@@ -243,6 +246,29 @@ __global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneP
             work_next = base < total ? base : total;
             work_end = base + TRACE_WORK_CHUNK < total ? base + TRACE_WORK_CHUNK : total;
             if (base + TRACE_WORK_CHUNK >= total) exhausted = true;
+            if (MODE == MODE_PHOTON) {
+                // Light::emit (Light.h:8-13) for the whole chunk now, all lanes busy, into this wave's LDS
+                // slice: the rejection loop of Vec3::GetUnitRandVec (Vec3.h:57-65) then runs once per 128
+                // photons instead of in every bounce iteration that happens to refill a lane.
+                chunk_base = work_next;
+#pragma unroll 1
+                for (uint32_t e = (uint32_t)lane; e < TRACE_WORK_CHUNK; e += 64) {
+                    const unsigned long long item = chunk_base + e;
+                    if (item >= n_resume && item < work_end) {
+                        const uint32_t es = rng_sub(tp.rng, (uint32_t)(tp.fresh_first + (item - n_resume)), 0u, P_EMIT);
+                        double x = 0, y = 0, z = 0;
+                        for (uint32_t k = 0; k < 64; k++) {
+                            x = rng_u01(es, 3 * k + 0) * 2.0 + -1.0;
+                            y = rng_u01(es, 3 * k + 1) * 2.0 + -1.0;
+                            z = rng_u01(es, 3 * k + 2) * 2.0 + -1.0;
+                            const double m = x * x + y * y + z * z;
+                            if (!(m > 1 || m < SPPM_EPS)) break;
+                        }
+                        const d3 u = get_unit(mk(x, y, z));
+                        emit_dir[3 * e + 0] = u.x; emit_dir[3 * e + 1] = u.y; emit_dir[3 * e + 2] = u.z;
+                    }
+                }
+            }
         }
         if (idle && work_next < work_end) {
             const unsigned long long avail = work_end - work_next;
@@ -275,16 +301,8 @@ __global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneP
                         carry[0] = carry[1] = carry[2] = 1.0f;
                     } else {
                         const DevLight& L = tp.lights[(g / tp.per_round) % (unsigned long long)tp.n_lights];
-                        const uint32_t es = rng_sub(tp.rng, id, 0u, P_EMIT);
-                        double x = 0, y = 0, z = 0;
-                        for (uint32_t k = 0; k < 64; k++) {                               // Vec3::GetUnitRandVec, Vec3.h:57-65
-                            x = rng_u01(es, 3 * k + 0) * 2.0 + -1.0;
-                            y = rng_u01(es, 3 * k + 1) * 2.0 + -1.0;
-                            z = rng_u01(es, 3 * k + 2) * 2.0 + -1.0;
-                            const double m = x * x + y * y + z * z;
-                            if (!(m > 1 || m < SPPM_EPS)) break;
-                        }
-                        d = get_unit(mk(x, y, z));
+                        const uint32_t e = (uint32_t)(my - chunk_base);                   // the direction drawn when the chunk was claimed
+                        d = mk(emit_dir[3 * e + 0], emit_dir[3 * e + 1], emit_dir[3 * e + 2]);
                         o = ld3(L.pos);                                                   // Light::emit, Light.h:8-13
                         carry[0] = L.flux[0]; carry[1] = L.flux[1]; carry[2] = L.flux[2];
                         nphot++;
@@ -1194,8 +1212,10 @@ static int close_chunks(sppm_ctx* ctx, Deposit* dep, RawHit* hits, uint64_t cap)
 
 template <int MODE>
 static void launch_trace(sppm_ctx* ctx, bool coop, int blocks, const SceneParams& sp, const TraceParams& tp) {
-    if (coop) hipLaunchKernelGGL((k_trace<MODE, true>), dim3(blocks), dim3(256), (size_t)ctx->blob_bytes, ctx->stream, sp, tp);
-    else hipLaunchKernelGGL((k_trace<MODE, false>), dim3(blocks), dim3(256), (size_t)ctx->blob_bytes, ctx->stream, sp, tp);
+    // dynamic LDS: the scene tables, then (photon pass) 4 waves x 128 emission directions
+    const size_t lds = (((size_t)ctx->blob_bytes + 15) & ~(size_t)15) + (MODE == MODE_PHOTON ? 4 * 128 * 3 * sizeof(double) : 0);
+    if (coop) hipLaunchKernelGGL((k_trace<MODE, true>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
+    else hipLaunchKernelGGL((k_trace<MODE, false>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
 }
 static int launch_trace_mode(sppm_ctx* ctx, int mode, bool coop, int blocks, const TraceParams& tp) {
     const SceneParams sp = ctx->scene_params();
