@@ -58,7 +58,8 @@ struct SceneParams {
 
 struct DevCounters {
     unsigned long long photons, segments, deposits, candidates, accepted, newton_calls, eye_segments;
-    unsigned int overflow;   // bit0 hitpoint capacity, bit1 eye task queue, bit2 deposit capacity
+    unsigned long long stamps[8];   // cycle sums per trace-loop section, filled by -DTRACE_STAMPS diagnostic builds only
+    unsigned int overflow;   // bit0 hitpoint capacity, bit1 eye task queue, bit2 deposit capacity (sticky: see overflow_code)
     unsigned int pad;
 };
 
@@ -169,6 +170,12 @@ __device__ __forceinline__ unsigned long long chunk_alloc(bool want, unsigned lo
 #ifndef TRACE_COOP_OCC
 #define TRACE_COOP_OCC 2
 #endif
+#ifdef TRACE_STAMPS
+#define STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
+                      st_sum[i] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 enum { MODE_EYE = 0, MODE_PHOTON = 1 };
 #ifndef TRACE_WORK_CHUNK_EYE
 #define TRACE_WORK_CHUNK_EYE 128u
@@ -236,7 +243,13 @@ __global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneP
     const uint32_t wave_slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     slot_next = tp.wave_chunks[2 * wave_slot];
     slot_end = tp.wave_chunks[2 * wave_slot + 1];
+#ifdef TRACE_STAMPS
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     for (;;) {
+        STAMP(7);
         // ---- refill idle lanes
         const uint64_t idle = __ballot(!active);
         if (idle && work_next >= work_end && !exhausted) {
@@ -310,6 +323,7 @@ __global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneP
                 }
             }
         }
+        STAMP(0);
         if (!__any(active)) {
             if (exhausted && work_next >= work_end) break;
             continue;   // the chunk ran dry mid-refill: claim the next one
@@ -324,8 +338,10 @@ __global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneP
             Near a;
             near_init(a);
             analytic_nearest(S, tracing, o, d, a);
+            STAMP(1);
             if (COOP) {
                 bezier_nearest_coop(S, tracing, o, d, sub, a, ncalls);
+                STAMP(2);
             } else {
                 bezier_patch_masks(S, tracing, o, d, words);
                 park = tracing && ((words[0] | words[1] | words[2] | words[3]) != 0);
@@ -388,7 +404,9 @@ __global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneP
         // ---- the hit (or miss) of every lane still active
         Near fin = nr;
         if (!active) near_init(fin);
+        STAMP(3);
         const Hit hit = finish_hit(S, o, d, fin);
+        STAMP(4);
         if (active) nseg++;
         if (active && hit.obj < 0) active = false;
 
@@ -492,7 +510,11 @@ __global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneP
                 } else atomicOr(&tp.counters->overflow, 4u);
             }
         }
+        STAMP(5);
     }
+#ifdef TRACE_STAMPS
+    if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&tp.counters->stamps[i], st_sum[i]);
+#endif
     if (lane == 0) {   // the open chunk stays with this wave slot for the next launch of the pass / batch
         tp.wave_chunks[2 * wave_slot] = slot_next;
         tp.wave_chunks[2 * wave_slot + 1] = slot_end;
@@ -1553,6 +1575,9 @@ int sppm_get_counters(sppm_ctx* ctx, sppm_counters* out) {
     out->photons = dc.photons; out->segments = dc.segments; out->deposits = dc.deposits;
     out->candidates = dc.candidates; out->accepted = dc.accepted; out->hitpoints = ctx->n_hp;
     out->newton_calls = dc.newton_calls; out->eye_segments = dc.eye_segments;
+    if (ctx->verbose && dc.stamps[0])
+        fprintf(stderr, "[sppm] trace loop cycles: refill %llu analytic %llu bezier %llu merge/park %llu finish %llu bounce %llu loop %llu\n",
+                dc.stamps[0], dc.stamps[1], dc.stamps[2], dc.stamps[3], dc.stamps[4], dc.stamps[5], dc.stamps[7]);
     ctx->check_pending = false;
     if (overflow_code(ctx, dc) != SPPM_OK) return fail(ctx, SPPM_E_CAPACITY, "a ray / task / deposit queue overflowed in an earlier pass");
     return SPPM_OK;
