@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=0, help="rounds per GPU per step (default: the config's)")
     ap.add_argument("--cpu-rounds", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("SPPM_INFLIGHT", "1")),
+                    help="replica iterations in flight per GPU (one context = one HIP stream each)")
     args = ap.parse_args()
 
     import torch
@@ -117,15 +119,18 @@ def main():
     rounds = args.rounds or cfg_rounds
     scene = factory()
     cam = scenes.default_camera(w, h)
-    ctx = SppmContext(local_rank)
-    ctx.set_scene(scene)
+    ctxs = [SppmContext(local_rank) for _ in range(max(1, args.inflight))]
+    for c in ctxs:
+        c.set_scene(scene)
+    ctx = ctxs[0]
     n_lights = len(scene.light_list)
     per_rank = rounds * per_round * n_lights
     total_rounds = rounds * world
-    pic = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    pics = [torch.zeros((h, w, 3), dtype=torch.float32, device="cuda") for _ in ctxs]
 
     def step(i):
-        D.sharded_iteration(ctx, cam, SEED, i, total_rounds, per_round, n_lights, rank, world, pic_tensor=pic)
+        k = i % len(ctxs)
+        D.sharded_iteration(ctxs[k], cam, SEED, i, total_rounds, per_round, n_lights, rank, world, pic_tensor=pics[k])
 
     def fence():
         if world > 1:
@@ -135,19 +140,23 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    ctx.stats_mode(True)        # counters and HIP-event spans accumulate over the timed steps: no per-step readback
+    for c in ctxs:
+        c.stats_mode(True)      # counters and HIP-event spans accumulate over the timed steps: no per-step readback
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
-    ctx.synchronize()           # waits for the library's stream and raises if a queued pass overflowed
+    for c in ctxs:
+        c.synchronize()         # waits for the library's stream and raises if a queued pass overflowed
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    tm = ctx.timings()              # HIP-event durations measured on the library's stream, summed over the timed steps
-    counters = ctx.counters()       # tallies of the timed steps
+    # HIP-event durations measured on the library's stream(s) and tallies, summed over the timed steps
+    tms, cnts = [c.timings() for c in ctxs], [c.counters() for c in ctxs]
+    tm = {k: sum(t[k] for t in tms) for k in tms[0]}
+    counters = {k: (sum(c[k] for c in cnts) if k != "hitpoints" else cnts[0][k]) for k in cnts[0]}
     acc = {k: tm[k] for k in ("eye_trace_ms", "grid_build_ms", "photon_trace_ms", "deposit_sort_ms", "gather_ms", "resolve_ms")}
     gather_launches = tm["gather_launches"]
     bytes_model = 40.0 * counters["candidates"] + 32.0 * counters["accepted"] + 64.0 * counters["segments"]
@@ -163,7 +172,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 rays/gather + f32 Newton/flux", "data": "synthetic",
-            "config": {"workload": f"{args.config}: teapot.bpt Cornell scene {w}x{h}, {per_rank} photons/iter/GPU "
+            "config": {"inflight": len(ctxs), "workload": f"{args.config}: teapot.bpt Cornell scene {w}x{h}, {per_rank} photons/iter/GPU "
                                    f"({rounds} rounds x {per_round}), one replica per step, photon-sharded over {world} GPU(s)",
                        "hitpoints": counters["hitpoints"]},
             "photon_pass_mphotons_per_s": per_rank * args.steps / pass_s / 1e6 if pass_s > 0 else None,
@@ -181,7 +190,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, w, h, args.cpu_rounds, 4)
         print(json.dumps(out), flush=True)
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
