@@ -1,6 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — SPPM hot path on MI355X: Mphotons/s and ms per SPPM iteration.
 
+Two replica iterations are in flight per GPU by default (`--inflight 2`: two library contexts =
+two HIP streams, used alternately), the way the reference keeps four replicas in flight with its
+OpenMP loop (Raytracer.h:442): the latency-bound eye pass of one iteration overlaps the photon pass
+of the other.  `--inflight 1` runs them strictly one after the other (per-kernel HIP-event
+durations are then undisturbed by the neighbour stream).
+
 One step = one SPPM iteration of one replica on the teapot Cornell scene at 800x600
 (eye pass + HitPoint grid + photon pass + resolve, plus the all-reduce of the flux image
 when N > 1).  Every rank traces 1 M photons per step (rounds = 10000 x 100 per GPU,
@@ -89,13 +95,13 @@ def measured_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c2_teapot_800x600")
     ap.add_argument("--rounds", type=int, default=0, help="rounds per GPU per step (default: the config's)")
-    ap.add_argument("--cpu-rounds", type=int, default=1000)
+    ap.add_argument("--cpu-rounds", type=int, default=4000, help="photon rounds (x100 photons) per CPU replica: ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("SPPM_INFLIGHT", "1")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("SPPM_INFLIGHT", "2")),
                     help="replica iterations in flight per GPU (one context = one HIP stream each)")
     args = ap.parse_args()
 
@@ -137,6 +143,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up: every context allocates its buffers in its first iteration; keep that out of warm-up and timing
+    for k in range(len(ctxs)):
+        D.sharded_iteration(ctxs[k], cam, SEED, 0, total_rounds, per_round, n_lights, rank, world, pic_tensor=pics[k])
+    fence()
     for i in range(args.warmup):
         step(i)
     fence()
