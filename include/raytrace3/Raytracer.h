@@ -9,7 +9,9 @@
 //   SPPM_ONETIME  photons per round and light           (100,   Raytracer.h:218)
 //   SPPM_ITERS    outer SPPM iterations                 (100000, Raytracer.h:425)
 //   SPPM_SEED     seed of the counter-based streams     (20260101)
-//   SPPM_DEVICES  comma-separated GPU ids for replicas  ("0")
+//   SPPM_DEVICES  comma-separated GPU ids, one library context (= HIP stream) per entry; the four
+//                 replicas of an iteration are dealt over them.  Default "0,0": two contexts on GPU 0,
+//                 so the eye pass of one replica overlaps the photon pass of another.
 #pragma once
 #include <cstdio>
 #include <cstdlib>
@@ -36,15 +38,6 @@ namespace sppm_host {
 inline long long env_ll(const char* name, long long dflt) {
     const char* e = std::getenv(name);
     return (e && *e) ? std::atoll(e) : dflt;
-}
-inline std::vector<int> env_devices() {
-    std::vector<int> d;
-    const char* e = std::getenv("SPPM_DEVICES");
-    std::stringstream ss(e && *e ? e : "0");
-    std::string tok;
-    while (std::getline(ss, tok, ',')) if (!tok.empty()) d.push_back(std::atoi(tok.c_str()));
-    if (d.empty()) d.push_back(0);
-    return d;
 }
 // Tone-mapped running mean as a binary PPM: rows flipped, and val[0] written as blue, which
 // is what the reference's BGR cv::Mat shows (Raytracer.h:460-470).
@@ -100,7 +93,7 @@ public:
     Camera* camera = nullptr;
     Scene* scene = nullptr;
     vector<HitPoint*> Hvec;
-    int device = 0;                       // GPU this tracer renders on
+    int device = 0;                       // context slot this tracer renders on (entry of SPPM_DEVICES)
     uint64_t seed = (uint64_t)sppm_host::env_ll("SPPM_SEED", 20260101);
     uint32_t replica = 0;                 // selects the random streams of this pass
 
@@ -197,7 +190,7 @@ public:
                 c[k].lookAt(camera.look, 1.);
                 rt[k].camera = &c[k];
                 rt[k].scene = &scene;
-                rt[k].device = devices[(size_t)k % devices.size()];
+                rt[k].device = (int)((size_t)k % devices.size());   // context slot, see sppm_host::Device::get
                 rt[k].replica = (uint32_t)(i * 4 + k);
             }
             std::vector<std::thread> th;

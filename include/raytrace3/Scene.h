@@ -3,6 +3,7 @@
 // the C-ABI structs of sppm_abi.h and keeps one GPU context per device.
 #pragma once
 #include <map>
+#include <sstream>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -64,8 +65,19 @@ inline void flatten(const std::vector<Obj*>& objvec, const std::vector<Light*>& 
     f.c.n_lights = (int)f.lights.size(); f.c.lights = f.lights.data();
 }
 
-// One GPU context per device id, created on first use; `mu` serialises callers because a
-// context serves one host thread at a time.
+// SPPM_DEVICES: comma-separated GPU ids, one context slot per entry (an id may repeat).
+inline std::vector<int> env_devices() {
+    std::vector<int> d;
+    const char* e = std::getenv("SPPM_DEVICES");
+    std::stringstream ss(e && *e ? e : "0,0");
+    std::string tok;
+    while (std::getline(ss, tok, ',')) if (!tok.empty()) d.push_back(std::atoi(tok.c_str()));
+    if (d.empty()) d.push_back(0);
+    return d;
+}
+
+// One library context per slot of SPPM_DEVICES, created on first use on that slot's GPU; `mu`
+// serialises callers because a context serves one host thread at a time.
 struct Device {
     sppm_ctx* ctx = nullptr;
     std::mutex mu;
@@ -81,16 +93,19 @@ struct Device {
         check(sppm_set_scene(ctx, &f.c), "sppm_set_scene");
         scene_tag = f.tag;
     }
-    static Device& get(int id) {
+    static Device& get(int slot_index) {
         static std::mutex reg_mu;
         static std::map<int, std::unique_ptr<Device>> reg;
+        static const std::vector<int> devices = env_devices();
         std::lock_guard<std::mutex> g(reg_mu);
-        auto& slot = reg[id];
+        const int key = (int)((size_t)(slot_index < 0 ? 0 : slot_index) % devices.size());
+        const int id = devices[(size_t)key];
+        auto& slot = reg[key];
         if (!slot) {
             slot.reset(new Device());
             int rc = sppm_create(&slot->ctx, id);
             if (rc != SPPM_OK) {
-                reg.erase(id);
+                reg.erase(key);
                 throw std::runtime_error("sppm_create failed: no usable GPU " + std::to_string(id) + " (there is no CPU fallback)");
             }
         }

@@ -58,3 +58,31 @@ def test_cpp_host_matches_python_host_and_oracle(tmp_path):
     c = o.resolve()
     diff = np.abs(cpp - c).max(axis=2) / c.mean()
     assert (diff <= 1e-3).mean() >= 0.97 and diff.mean() <= 2e-3
+
+
+def _read_ppm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"P6"
+        w, h = map(int, f.readline().split())
+        assert int(f.readline()) == 255
+        return np.frombuffer(f.read(), dtype=np.uint8).reshape(h, w, 3)
+
+
+@pytest.mark.gpu
+def test_sppm_loop_over_one_and_two_contexts(tmp_path):
+    """SPPMRayTracer::render (Raytracer.h:421-477) through the drop-in classes: four replicas per
+    iteration on threads.  One context (replicas one after the other) and two contexts on the same GPU
+    (eye pass of one replica overlapping the photon pass of another) give the same picture."""
+    exe = os.path.join(ROOT, "examples", "_build", "sppm_main")
+    pics = []
+    for devices in ("0", "0,0"):
+        d = tmp_path / ("dev_" + devices.replace(",", "_"))
+        d.mkdir()
+        env = dict(os.environ, SPPM_SEED="5", SPPM_W="64", SPPM_H="48", SPPM_ITERS="2", SPPM_ROUNDS="40",
+                   SPPM_DEVICES=devices, SPPM_DATA_DIR=os.path.join(ROOT, "raytrace3_amd", "data"))
+        r = subprocess.run([exe], capture_output=True, text=True, env=env, cwd=str(d), timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        pics.append(_read_ppm(d / "aaanew0.ppm"))
+    a, b = pics
+    assert a.shape == (48, 64, 3) and a.max() > 50          # something was rendered
+    assert np.abs(a.astype(int) - b.astype(int)).max() <= 1  # fp32 summation order only
