@@ -64,7 +64,10 @@ struct SceneView {
     const DevObject* objs;      // LDS
     const double* patch_box;    // LDS, n_patches x 6 (pmin, pmax)
     const float* patch_cp;      // LDS, n_patches x 48
-    const float* patch_cp_global;   // the same table in global memory: wave-uniform reads of it become scalar loads
+    // Newton tables in GLOBAL memory (wave-uniform reads of them become scalar loads): per patch the 48
+    // power-basis coefficients of S(u,v) - centre, and the centre (see newton_coop)
+    const float* pw_q;
+    const double* pw_c;
     const int* patch_obj;       // LDS, n_patches: owning object of each patch
     int n_objs;
     int n_patches;
@@ -266,16 +269,58 @@ __device__ __forceinline__ f3 patch_point(const float* P, float u, float v) {
     return S;
 }
 
+// The patch in the form the Newton solver evaluates: S(u,v) - c = sum_j sum_i Q[j][i] u^i v^j, the bicubic
+// of Bezier.h:69-111 expanded from the Bernstein to the power basis around the patch centre c (done once per
+// scene on the host, in fp64).  Horner evaluation of S, dS/du, dS/dv costs ~115 fp32 operations instead of
+// ~160 in Bernstein form, and coordinates relative to the centre are a few units instead of ~100, so the fp32
+// residual org + dir t - S(u,v) is formed from small numbers.  Q: 48 wave-uniform values (SGPRs).
+__device__ __forceinline__ void patch_eval_pw(const float* Q, float u, float v, f3& S, f3& Su, f3& Sv) {
+    const float u2 = u * u, u3 = u2 * u, w1 = 2.0f * u, w2 = 3.0f * u2;
+    const float x1 = 2.0f * v, x2 = 3.0f * v * v;
+    float A[4][3], D[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float q0 = Q[(j * 4 + 0) * 3 + c], q1 = Q[(j * 4 + 1) * 3 + c], q2 = Q[(j * 4 + 2) * 3 + c], q3 = Q[(j * 4 + 3) * 3 + c];
+            A[j][c] = q0 + (q1 * u + (q2 * u2 + q3 * u3));
+            D[j][c] = q1 + (q2 * w1 + q3 * w2);
+        }
+    float s[3], su[3], sv[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        s[c] = A[0][c] + v * (A[1][c] + v * (A[2][c] + v * A[3][c]));
+        su[c] = D[0][c] + v * (D[1][c] + v * (D[2][c] + v * D[3][c]));
+        sv[c] = A[1][c] + (x1 * A[2][c] + x2 * A[3][c]);
+    }
+    S = {s[0], s[1], s[2]}; Su = {su[0], su[1], su[2]}; Sv = {sv[0], sv[1], sv[2]};
+}
+__device__ __forceinline__ f3 patch_point_pw(const float* Q, float u, float v) {
+    const float u2 = u * u, u3 = u2 * u;
+    float A[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            A[j][c] = Q[(j * 4 + 0) * 3 + c] + (Q[(j * 4 + 1) * 3 + c] * u + (Q[(j * 4 + 2) * 3 + c] * u2 + Q[(j * 4 + 3) * 3 + c] * u3));
+    f3 S;
+    S.x = A[0][0] + v * (A[1][0] + v * (A[2][0] + v * A[3][0]));
+    S.y = A[0][1] + v * (A[1][1] + v * (A[2][1] + v * A[3][1]));
+    S.z = A[0][2] + v * (A[1][2] + v * (A[2][2] + v * A[3][2]));
+    return S;
+}
+
 // One Newton restart, Bezier.h:117-140: 10 steps of x -= J^-1 (org + dir t - S(u,v)),
 // J = [dir | -Su | -Sv], from (0, u0, v0); every iterate with residual^2 < 1e-4 and
 // u, v in [0,1] is a candidate; returns this restart's first minimum-t candidate.
-__device__ __forceinline__ void newton_restart(const float* P, f3 o, f3 d, float u0, float v0, float& best_t, float& best_u, float& best_v) {
+// Q: the patch in power form around its centre; o: ray origin relative to that centre.
+__device__ __forceinline__ void newton_restart(const float* Q, f3 o, f3 d, float u0, float v0, float& best_t, float& best_u, float& best_v) {
     float t = 0.0f, u = u0, v = v0;
     best_t = (float)SPPM_MAX_NUM; best_u = 0; best_v = 0;
 #pragma unroll 1
     for (int it = 0; it < SPPM_NEWTON_ITERS; it++) {
         f3 S, Su, Sv;
-        patch_eval(P, u, v, S, Su, Sv);
+        patch_eval_pw(Q, u, v, S, Su, Sv);
         float rx = o.x + d.x * t - S.x, ry = o.y + d.y * t - S.y, rz = o.z + d.z * t - S.z;
         if (it > 0) {  // candidate test of the iterate produced by the previous step (Bezier.h:133-139)
             float res2 = rx * rx + ry * ry + rz * rz;
@@ -293,7 +338,7 @@ __device__ __forceinline__ void newton_restart(const float* P, f3 o, f3 d, float
         u -= (c1x * rx + c1y * ry + c1z * rz) * inv;
         v -= (c2x * rx + c2y * ry + c2z * rz) * inv;
     }
-    f3 S = patch_point(P, u, v);
+    f3 S = patch_point_pw(Q, u, v);
     float rx = o.x + d.x * t - S.x, ry = o.y + d.y * t - S.y, rz = o.z + d.z * t - S.z;
     float res2 = rx * rx + ry * ry + rz * rz;
     if (res2 < (float)SPPM_EPS && u <= 1.0f && u >= 0.0f && v >= 0.0f && v <= 1.0f && t < best_t) {
@@ -304,21 +349,26 @@ __device__ __forceinline__ void newton_restart(const float* P, f3 o, f3 d, float
 // Bezier3::newton (Bezier.h:112-159) for ONE (ray, patch), all 64 lanes cooperating:
 // lane r < 50 runs restart r; the result is the minimum-t candidate over all
 // restarts, ties to the lowest restart (the reference keeps the first pushed
-// minimum).  o, d, sub (the ray's NEWTON hash state) and patch are wave-uniform.
+// minimum).  so, sd (the ray, fp64), sub (the ray's NEWTON hash state) and patch are wave-uniform.
 // Returns a wave-uniform (t,u,v); t = 1e20 when nothing converged.
-// cp is the control-point table in GLOBAL memory: with a wave-uniform patch index the 48 reads are scalar
-// loads and the control points live in SGPRs for the whole solve (no vector registers spent on them).
-__device__ __forceinline__ void newton_coop(const float* __restrict__ cp, int patch, f3 o, f3 d, uint32_t sub, float& rt, float& ru, float& rv) {
+// pw_q / pw_c are GLOBAL memory: with a wave-uniform patch index the reads are scalar loads and
+// the 48 coefficients live in SGPRs for the whole solve (no vector registers spent on them).
+__device__ __forceinline__ void newton_coop(const float* __restrict__ pw_q, const double* __restrict__ pw_c, int patch, d3 so, d3 sd,
+                                            uint32_t sub, float& rt, float& ru, float& rv) {
     const int lane = lane_id();
-    float P[48];
-    const float* src = cp + __builtin_amdgcn_readfirstlane(patch) * 48;
+    patch = __builtin_amdgcn_readfirstlane(patch);
+    float Q[48];
+    const float* src = pw_q + patch * 48;
 #pragma unroll
-    for (int k = 0; k < 48; k++) P[k] = src[k];
+    for (int k = 0; k < 48; k++) Q[k] = src[k];
+    const double* c = pw_c + patch * 3;
+    const f3 o = {(float)(so.x - c[0]), (float)(so.y - c[1]), (float)(so.z - c[2])};   // origin relative to the patch centre, rounded once
+    const f3 d = {(float)sd.x, (float)sd.y, (float)sd.z};
     float bt = (float)SPPM_MAX_NUM, bu = 0, bv = 0;
     if (lane < SPPM_NEWTON_RESTARTS) {
         float u0 = rng_u01f(sub, (uint32_t)patch * 128u + (uint32_t)lane * 2u + 0u);
         float v0 = rng_u01f(sub, (uint32_t)patch * 128u + (uint32_t)lane * 2u + 1u);
-        newton_restart(P, o, d, u0, v0, bt, bu, bv);
+        newton_restart(Q, o, d, u0, v0, bt, bu, bv);
     }
     // min over lanes of (t, lane)
     int who = lane;
@@ -351,7 +401,6 @@ __device__ __forceinline__ void bezier_coop(const SceneView& S, const DevObject&
         d3 so = mk(bcast_d(o.x, src), bcast_d(o.y, src), bcast_d(o.z, src));
         d3 sd = mk(bcast_d(d.x, src), bcast_d(d.y, src), bcast_d(d.z, src));
         uint32_t ssub = bcast_u(sub, src);
-        f3 fo = {(float)so.x, (float)so.y, (float)so.z}, fd = {(float)sd.x, (float)sd.y, (float)sd.z};
         float pt = (float)SPPM_MAX_NUM, pu = (float)SPPM_MAX_NUM, pv = (float)SPPM_MAX_NUM;  // para = MAX_VEC3
         int pidx = -1;
         for (int base = 0; base < n_patches; base += 64) {
@@ -362,7 +411,7 @@ __device__ __forceinline__ void bezier_coop(const SceneView& S, const DevObject&
                 int pi = first_patch + base + (__ffsll((unsigned long long)pm) - 1);
                 pm &= pm - 1;
                 float t, u, v;
-                newton_coop(S.patch_cp_global, pi, fo, fd, ssub, t, u, v);
+                newton_coop(S.pw_q, S.pw_c, pi, so, sd, ssub, t, u, v);
                 newton_calls += (lane == 0) ? 1u : 0u;
                 const float e = (float)SPPM_EPS;
                 // Bezier.h:251-259 (a patch whose minimum-t candidate is negative is dropped as a whole)

@@ -54,6 +54,8 @@ struct SceneParams {
     int blob_bytes, off_box, off_cp, off_pobj, n_objs, n_patches;
     const TexDesc* tex;
     const uchar4* texels;
+    const float* pw_q;      // Newton tables: power-basis coefficients around the patch centre, n_patches x 48
+    const double* pw_c;     // and the centres, n_patches x 3
 };
 
 struct DevCounters {
@@ -100,7 +102,8 @@ __device__ __forceinline__ SceneView stage_scene(const SceneParams& sp) {
     S.objs = (const DevObject*)base;
     S.patch_box = (const double*)(base + sp.off_box);
     S.patch_cp = (const float*)(base + sp.off_cp);
-    S.patch_cp_global = (const float*)(sp.blob + sp.off_cp);
+    S.pw_q = sp.pw_q;
+    S.pw_c = sp.pw_c;
     S.patch_obj = (const int*)(base + sp.off_pobj);
     S.n_objs = sp.n_objs;
     S.n_patches = sp.n_patches;
@@ -534,16 +537,16 @@ __global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneP
 // lane r < 50 = restart r, control points read from global memory with a wave-uniform address.
 __global__ void __launch_bounds__(256) k_newton(const ParkRec* __restrict__ park, const NewtonTask* __restrict__ tasks,
                                                 const unsigned long long* __restrict__ n_tasks_dev, unsigned long long task_cap,
-                                                const float* __restrict__ patches, float4* __restrict__ res, DevCounters* counters) {
+                                                const float* __restrict__ pw_q, const double* __restrict__ pw_c,
+                                                float4* __restrict__ res, DevCounters* counters) {
     const uint32_t n_tasks = (uint32_t)min(*n_tasks_dev, task_cap);
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     uint32_t done = 0;
     for (uint32_t t = wave; t < n_tasks; t += n_waves) {
         const uint32_t pk = __builtin_amdgcn_readfirstlane(tasks[t].park), patch = __builtin_amdgcn_readfirstlane(tasks[t].patch);
         const ParkRec& r = park[pk];
-        const f3 fo = {(float)r.o[0], (float)r.o[1], (float)r.o[2]}, fd = {(float)r.d[0], (float)r.d[1], (float)r.d[2]};
         float rt, ru, rv;
-        newton_coop(patches, (int)patch, fo, fd, r.sub, rt, ru, rv);
+        newton_coop(pw_q, pw_c, (int)patch, ld3(r.o), ld3(r.d), r.sub, rt, ru, rv);
         if (lane_id() == 0) { res[t] = make_float4(rt, ru, rv, 0.0f); done++; }
     }
     flush_counter(&counters->newton_calls, done);
@@ -884,10 +887,10 @@ __global__ void __launch_bounds__(256) k_debug_newton(SceneParams sp, uint32_t n
     while (m) {
         int src = __ffsll((unsigned long long)m) - 1;
         m &= m - 1;
-        f3 fo = {(float)bcast_d(ox, src), (float)bcast_d(oy, src), (float)bcast_d(oz, src)};
-        f3 fd = {(float)bcast_d(dx, src), (float)bcast_d(dy, src), (float)bcast_d(dz, src)};
+        const d3 so = mk(bcast_d(ox, src), bcast_d(oy, src), bcast_d(oz, src));
+        const d3 sd = mk(bcast_d(dx, src), bcast_d(dy, src), bcast_d(dz, src));
         float t, u, v;
-        newton_coop(S.patch_cp_global, bcast_i(p, src), fo, fd, bcast_u(sub, src), t, u, v);
+        newton_coop(S.pw_q, S.pw_c, bcast_i(p, src), so, sd, bcast_u(sub, src), t, u, v);
         if (lane == src && t < (float)SPPM_MAX_NUM) { mt = t; mu = u; mv = v; }
     }
     if (active) {
@@ -929,6 +932,7 @@ struct sppm_ctx {
     bool have_scene = false;
     DevBuf<char> blob; int blob_bytes = 0, off_box = 0, off_cp = 0, off_pobj = 0, n_objs = 0, n_patches = 0;
     DevBuf<TexDesc> tex; DevBuf<uchar4> texels;
+    DevBuf<float> pw_q; DevBuf<double> pw_c;   // Newton tables (power basis around the patch centres)
     DevBuf<DevLight> lights; int n_lights = 0;
     // eye pass
     bool have_eye = false;
@@ -979,6 +983,7 @@ struct sppm_ctx {
         SceneParams sp;
         sp.blob = blob.p; sp.blob_bytes = blob_bytes; sp.off_box = off_box; sp.off_cp = off_cp; sp.off_pobj = off_pobj;
         sp.n_objs = n_objs; sp.n_patches = n_patches; sp.tex = tex.p; sp.texels = texels.p;
+        sp.pw_q = pw_q.p; sp.pw_c = pw_c.p;
         return sp;
     }
 };
@@ -1072,6 +1077,7 @@ void sppm_destroy(sppm_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    ctx->pw_q.release(); ctx->pw_c.release();
     ctx->blob.release(); ctx->tex.release(); ctx->texels.release(); ctx->lights.release();
     ctx->raw.release(); ctx->park[0].release(); ctx->park[1].release(); ctx->ntask[0].release(); ctx->ntask[1].release(); ctx->nres.release();
     ctx->bucket_of.release(); ctx->hist.release(); ctx->hstart.release();
@@ -1152,6 +1158,30 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
                 }
             }
         }
+    }
+    // Newton tables: Bernstein -> power basis around the patch centre, in fp64 (patch_eval_pw)
+    {
+        static const double Mb[4][4] = {{1, 0, 0, 0}, {-3, 3, 0, 0}, {3, -6, 3, 0}, {-1, 3, -3, 1}};   // u^i = sum_a Mb[i][a] P_a
+        std::vector<float> q((size_t)std::max(1, np) * 48, 0.0f);
+        std::vector<double> cen((size_t)std::max(1, np) * 3, 0.0);
+        for (int p = 0; p < np; p++) {
+            double c[3];
+            for (int k = 0; k < 3; k++) c[k] = 0.5 * (box[6 * p + k] + box[6 * p + 3 + k]);
+            for (int j = 0; j < 4; j++)
+                for (int i = 0; i < 4; i++)
+                    for (int k = 0; k < 3; k++) {
+                        double acc = 0;
+                        for (int b2 = 0; b2 < 4; b2++)
+                            for (int a2 = 0; a2 < 4; a2++)
+                                acc += Mb[j][b2] * Mb[i][a2] * (s->patches[(size_t)p * 48 + (b2 * 4 + a2) * 3 + k] - c[k]);
+                        q[(size_t)p * 48 + (j * 4 + i) * 3 + k] = (float)acc;
+                    }
+            for (int k = 0; k < 3; k++) cen[(size_t)p * 3 + k] = c[k];
+        }
+        HIPCHK(ctx->pw_q.reserve(q.size()));
+        HIPCHK(hipMemcpy(ctx->pw_q.p, q.data(), q.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(ctx->pw_c.reserve(cen.size()));
+        HIPCHK(hipMemcpy(ctx->pw_c.p, cen.data(), cen.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     HIPCHK(ctx->blob.reserve((size_t)bytes));
     HIPCHK(hipMemcpy(ctx->blob.p, blob.data(), (size_t)bytes, hipMemcpyHostToDevice));
@@ -1306,7 +1336,7 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
     };
     auto launch_newton = [&](int cur) -> int {
         hipLaunchKernelGGL(k_newton, dim3(ctx->num_cu * ctx->newton_blocks_per_cu), dim3(256), 0, ctx->stream, ctx->park[cur].p,
-                           ctx->ntask[cur].p, task_ctr(cur), (unsigned long long)task_cap, (const float*)(ctx->blob.p + ctx->off_cp),
+                           ctx->ntask[cur].p, task_ctr(cur), (unsigned long long)task_cap, ctx->pw_q.p, ctx->pw_c.p,
                            ctx->nres.p, ctx->counters.p);
         HIPCHK(hipGetLastError());
         return SPPM_OK;
