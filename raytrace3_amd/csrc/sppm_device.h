@@ -226,6 +226,28 @@ __device__ __forceinline__ bool aabb_hit(const double* __restrict__ box, d3 o, d
     return false;
 }
 
+// Lower bound of the ray parameter of every ray point that lies within `margin` of the box (slab test on
+// the box grown by margin; 0 if the ray starts inside it).  A Newton candidate of a patch is a ray point
+// whose distance to S(u,v), u,v in [0,1], is below sqrt(1e-4) = 0.01 (Bezier.h:135), and S(u,v) lies in the
+// convex hull of the control points, hence in the patch box: its t is >= this bound for margin > 0.01.
+// A patch whose bound exceeds a hit already found can therefore be skipped without changing the result of
+// Bezier3Obj::GetIntersect / Scene::NearCollide (both keep the nearest hit).
+#define SPPM_PRUNE_MARGIN 0.011
+#define SPPM_PRUNE_SLACK 1e-3f
+__device__ __forceinline__ float aabb_entry_lb(const double* __restrict__ box, d3 o, d3 d) {
+    double t0 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double di = comp(d, i);
+        if (fabs(di) > 1e-12) {
+            const double inv = 1.0 / di;
+            const double a = (box[i] - SPPM_PRUNE_MARGIN - comp(o, i)) * inv, b = (box[3 + i] + SPPM_PRUNE_MARGIN - comp(o, i)) * inv;
+            t0 = fmax(t0, fmin(a, b));
+        }
+    }
+    return (float)t0;
+}
+
 // ------------------------------------------------------------------ bicubic Bernstein evaluation (Bezier.h:69-111), fp32
 // S(u,v) = sum_i sum_k P[4i+k] b_k(u) b_i(v): u runs along the fast index.
 struct f3 { float x, y, z; };
@@ -386,10 +408,12 @@ __device__ __forceinline__ void newton_coop(const float* __restrict__ pw_q, cons
 
 // ------------------------------------------------------------------ Scene::NearCollide (Scene.h:165-182)
 // Bezier3Obj::GetIntersect (Bezier.h:240-282) for the lanes of one wave.  `need` marks
-// lanes whose ray passed the object AABB.  For each such ray in turn the wave tests the
-// patch AABBs one per lane, then solves every hit patch cooperatively.  On return the
-// ray's lane holds (t,u,v,patch) of the nearest accepted patch or patch = -1.
-__device__ __forceinline__ void bezier_coop(const SceneView& S, const DevObject& ob, bool need, d3 o, d3 d, uint32_t sub,
+// lanes whose ray passed the object AABB; `bound` is the distance of the nearest hit the lane's ray has
+// so far (other objects).  For each such ray in turn the wave tests the patch AABBs one per lane, then
+// solves the hit patches cooperatively, nearest box first, and stops as soon as no remaining box can hold
+// a hit nearer than the best one (aabb_entry_lb).  On return the ray's lane holds (t,u,v,patch) of the
+// nearest accepted patch or patch = -1.
+__device__ __forceinline__ void bezier_coop(const SceneView& S, const DevObject& ob, bool need, d3 o, d3 d, uint32_t sub, float bound,
                                             float& out_t, float& out_u, float& out_v, int& out_patch, uint32_t& newton_calls) {
     const int lane = lane_id();
     out_patch = -1; out_t = (float)SPPM_MAX_NUM; out_u = 0; out_v = 0;
@@ -401,22 +425,34 @@ __device__ __forceinline__ void bezier_coop(const SceneView& S, const DevObject&
         d3 so = mk(bcast_d(o.x, src), bcast_d(o.y, src), bcast_d(o.z, src));
         d3 sd = mk(bcast_d(d.x, src), bcast_d(d.y, src), bcast_d(d.z, src));
         uint32_t ssub = bcast_u(sub, src);
+        const float sbound = bcast_f(bound, src);
         float pt = (float)SPPM_MAX_NUM, pu = (float)SPPM_MAX_NUM, pv = (float)SPPM_MAX_NUM;  // para = MAX_VEC3
         int pidx = -1;
         for (int base = 0; base < n_patches; base += 64) {
             int p = first_patch + base + lane;
             bool ph = (base + lane < n_patches) && aabb_hit(S.patch_box + 6 * p, so, sd);      // Bezier3::intersect, Bezier.h:176-186
+            // lb >= 0, so the bit patterns order like the values and the selection below runs on scalars
+            const uint32_t lbb = ph ? __float_as_uint(aabb_entry_lb(S.patch_box + 6 * p, so, sd)) : 0xffffffffu;
             uint64_t pm = __ballot(ph);
             while (pm) {
-                int pi = first_patch + base + (__ffsll((unsigned long long)pm) - 1);
-                pm &= pm - 1;
+                int sel = 0;
+                uint32_t selb = 0xffffffffu;
+                for (uint64_t q = pm; q; q &= q - 1) {
+                    const int bit = __ffsll((unsigned long long)q) - 1;
+                    const uint32_t v = bcast_u(lbb, bit);
+                    if (v < selb) { selb = v; sel = bit; }
+                }
+                if (__uint_as_float(selb) - SPPM_PRUNE_SLACK > fminf(pt, sbound)) break;   // nor can any box after it in this order
+                pm &= ~(1ull << sel);
+                const int pi = first_patch + base + sel;
                 float t, u, v;
                 newton_coop(S.pw_q, S.pw_c, pi, so, sd, ssub, t, u, v);
                 newton_calls += (lane == 0) ? 1u : 0u;
                 const float e = (float)SPPM_EPS;
-                // Bezier.h:251-259 (a patch whose minimum-t candidate is negative is dropped as a whole)
+                // Bezier.h:251-259 (a patch whose minimum-t candidate is negative is dropped as a whole); the
+                // reference walks the patches in index order and keeps the first minimum
                 if (t < e || t > pt || u < -e || u > 1 + e || v < -e || v > 1 + e) continue;
-                if (t < pt) { pt = t; pu = u; pv = v; pidx = pi; }
+                if (t < pt || (t == pt && pi < pidx)) { pt = t; pu = u; pv = v; pidx = pi; }
             }
         }
         if (lane == src) { out_t = pt; out_u = pu; out_v = pv; out_patch = pidx; }
@@ -481,7 +517,7 @@ __device__ __forceinline__ void bezier_nearest_coop(const SceneView& S, bool act
         bool need = active && aabb_hit(ob.bmin, o, d);
         float t, u, v;
         int patch;
-        bezier_coop(S, ob, need, o, d, newton_sub, t, u, v, patch, newton_calls);
+        bezier_coop(S, ob, need, o, d, newton_sub, (float)nr.dist, t, u, v, patch, newton_calls);
         if (need && patch >= 0) near_consider(nr, (double)t, a, 0, patch, t, u, v);
     }
 }

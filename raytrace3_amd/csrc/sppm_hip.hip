@@ -222,7 +222,7 @@ struct TraceParams {
 // from its record.  This keeps the 50 x 10 Newton iterations out of the divergent path loop.
 template <int MODE, bool COOP>
 __global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneParams sp, TraceParams tp) {
-    const unsigned long long n_resume = tp.resume ? *tp.n_resume_dev : 0ull;
+    const unsigned long long n_resume = tp.resume ? min(*tp.n_resume_dev, tp.park_cap) : 0ull;   // records beyond the capacity were never written
     const unsigned long long total = n_resume + tp.fresh_count;
     // the host sizes a resume launch without knowing its count: workgroups beyond the work leave at once
     if (blockIdx.x > 0 && (unsigned long long)blockIdx.x * blockDim.x >= total) return;
@@ -377,18 +377,20 @@ __global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneP
             const unsigned long long slot = wave_alloc(park, tp.n_park);
             const unsigned long long tb = wave_alloc_n(my_tasks, tp.n_tasks);
             if (park) {
-                if (slot < tp.park_cap && tb + my_tasks <= tp.task_cap) {
+                const bool tasks_fit = tb + my_tasks <= tp.task_cap;
+                if (!tasks_fit || slot >= tp.park_cap) atomicOr(&tp.counters->overflow, 2u);
+                if (slot < tp.park_cap) {   // a claimed record is always well formed (later launches read it whatever the flags say)
                     ParkRec r;
                     r.o[0] = o.x; r.o[1] = o.y; r.o[2] = o.z; r.d[0] = d.x; r.d[1] = d.y; r.d[2] = d.z;
                     r.adist = nr.dist; r.aobj = nr.obj; r.ainside = nr.inside;
                     r.carry[0] = carry[0]; r.carry[1] = carry[1]; r.carry[2] = carry[2];
                     r.id = id; r.dep = dep; r.node = node;
-                    r.task_first = (uint32_t)tb; r.task_count = my_tasks; r.sub = sub; r.pad = 0;
+                    r.task_first = (uint32_t)tb; r.task_count = tasks_fit ? my_tasks : 0u; r.sub = sub; r.pad = 0;
                     tp.park_out[slot] = r;
                     uint32_t k = 0;
 #pragma unroll
                     for (int w = 0; w < SPPM_MASK_WORDS; w++) {
-                        uint64_t m = words[w];
+                        uint64_t m = tasks_fit ? words[w] : 0ull;
                         while (m) {
                             const int bit = __ffsll((unsigned long long)m) - 1;
                             m &= m - 1;
@@ -533,21 +535,53 @@ __global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneP
     }
 }
 
-// Bezier3::newton (Bezier.h:112-159) for every task of a round: one wave per (ray, patch),
-// lane r < 50 = restart r, control points read from global memory with a wave-uniform address.
-__global__ void __launch_bounds__(256) k_newton(const ParkRec* __restrict__ park, const NewtonTask* __restrict__ tasks,
-                                                const unsigned long long* __restrict__ n_tasks_dev, unsigned long long task_cap,
-                                                const float* __restrict__ pw_q, const double* __restrict__ pw_c,
-                                                float4* __restrict__ res, DevCounters* counters) {
-    const uint32_t n_tasks = (uint32_t)min(*n_tasks_dev, task_cap);
+// Bezier3::newton (Bezier.h:112-159) for the parked rays of a round: one wave per ray at a time, on
+// long-lived waves.  The lanes look up the boxes of the ray's tasks (one task = one patch whose box the ray
+// enters), then the wave solves them nearest box first, lane r < 50 = restart r (newton_coop), and stops as
+// soon as no remaining box can hold a hit nearer than the best one found or than the plane / sphere hit the
+// ray already has (aabb_entry_lb).  Every task gets a result; (1e20, 0, 0) = nothing, or not needed.
+__global__ void __launch_bounds__(256) k_newton(const ParkRec* __restrict__ park, const unsigned long long* __restrict__ n_park_dev,
+                                                unsigned long long park_cap, const NewtonTask* __restrict__ tasks, unsigned long long task_cap,
+                                                const double* __restrict__ patch_box, const float* __restrict__ pw_q,
+                                                const double* __restrict__ pw_c, float4* __restrict__ res, DevCounters* counters) {
+    const uint32_t n_park = (uint32_t)min(*n_park_dev, park_cap);
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const int lane = lane_id();
     uint32_t done = 0;
-    for (uint32_t t = wave; t < n_tasks; t += n_waves) {
-        const uint32_t pk = __builtin_amdgcn_readfirstlane(tasks[t].park), patch = __builtin_amdgcn_readfirstlane(tasks[t].patch);
-        const ParkRec& r = park[pk];
-        float rt, ru, rv;
-        newton_coop(pw_q, pw_c, (int)patch, ld3(r.o), ld3(r.d), r.sub, rt, ru, rv);
-        if (lane_id() == 0) { res[t] = make_float4(rt, ru, rv, 0.0f); done++; }
+    for (uint32_t r = wave; r < n_park; r += n_waves) {
+        const ParkRec& rec = park[r];
+        const uint32_t first = __builtin_amdgcn_readfirstlane(rec.task_first), cnt = __builtin_amdgcn_readfirstlane(rec.task_count);
+        if (cnt == 0 || (unsigned long long)first + cnt > task_cap) continue;
+        const d3 so = ld3(rec.o), sd = ld3(rec.d);
+        const uint32_t sub = rec.sub;
+        float best = rec.aobj >= 0 ? (float)rec.adist : (float)SPPM_MAX_NUM;   // nearest hit so far; solved patches lower it
+        const float e = (float)SPPM_EPS;
+        for (uint32_t base = 0; base < cnt; base += 64) {
+            const uint32_t i = base + lane;
+            const bool valid = i < cnt;
+            const uint32_t patch = valid ? tasks[first + i].patch : 0u;
+            const uint32_t lbb = valid ? __float_as_uint(aabb_entry_lb(patch_box + 6 * (size_t)patch, so, sd)) : 0xffffffffu;
+            float rt = (float)SPPM_MAX_NUM, ru = 0, rv = 0;
+            uint64_t pm = __ballot(valid);
+            while (pm) {
+                int sel = 0;
+                uint32_t selb = 0xffffffffu;
+                for (uint64_t q = pm; q; q &= q - 1) {
+                    const int bit = __ffsll((unsigned long long)q) - 1;
+                    const uint32_t v = bcast_u(lbb, bit);
+                    if (v < selb) { selb = v; sel = bit; }
+                }
+                if (__uint_as_float(selb) - SPPM_PRUNE_SLACK > best) break;
+                pm &= ~(1ull << sel);
+                float t, u, v;
+                newton_coop(pw_q, pw_c, (int)bcast_u(patch, sel), so, sd, sub, t, u, v);
+                done += (lane == 0) ? 1u : 0u;
+                if (lane == sel) { rt = t; ru = u; rv = v; }
+                // what the per-patch filter of Bezier.h:251-259 would accept can lower the bound
+                if (!(t < e || u < -e || u > 1 + e || v < -e || v > 1 + e)) best = fminf(best, t);
+            }
+            if (valid) res[first + i] = make_float4(rt, ru, rv, 0.0f);
+        }
     }
     flush_counter(&counters->newton_calls, done);
 }
@@ -1336,8 +1370,8 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
     };
     auto launch_newton = [&](int cur) -> int {
         hipLaunchKernelGGL(k_newton, dim3(ctx->num_cu * ctx->newton_blocks_per_cu), dim3(256), 0, ctx->stream, ctx->park[cur].p,
-                           ctx->ntask[cur].p, task_ctr(cur), (unsigned long long)task_cap, ctx->pw_q.p, ctx->pw_c.p,
-                           ctx->nres.p, ctx->counters.p);
+                           park_ctr(cur), (unsigned long long)park_cap, ctx->ntask[cur].p, (unsigned long long)task_cap,
+                           (const double*)(ctx->blob.p + ctx->off_box), ctx->pw_q.p, ctx->pw_c.p, ctx->nres.p, ctx->counters.p);
         HIPCHK(hipGetLastError());
         return SPPM_OK;
     };

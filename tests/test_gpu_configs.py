@@ -154,7 +154,8 @@ def test_c4_reduced_against_oracle(gpu):
     assert same.mean() >= 0.995
     perr = np.abs(gm["pos"] - cm["pos"]).max(axis=1)[same]
     assert (perr <= 1e-3).mean() >= 0.97
-    assert gpu.counters()["newton_calls"] == pytest.approx(o.counters()["newton_calls"], rel=0.02)
+    # nearest-box-first with skipping of boxes that cannot hold a nearer hit: fewer solves, same hits
+    assert 0.2 * o.counters()["newton_calls"] <= gpu.counters()["newton_calls"] <= o.counters()["newton_calls"]
     _image_parity(gpu.resolve(), o.resolve(), frac=0.95, mae=4e-3)
 
 

@@ -114,6 +114,31 @@ def test_newton_golden_cases(gpu):
     assert np.median(err32) < 1e-4
 
 
+def test_bezier_nearest_hit_over_many_patches(gpu):
+    """Scene::NearCollide on the four-teapot scene (128 patches, teapots in front of each other): the GPU
+    solves the patches nearest box first and skips boxes that cannot hold a nearer hit, which must not change
+    which object is hit nor where."""
+    scene = scenes.scene_teapot(4, textured=False)
+    gpu.set_scene(scene)
+    o = _oracle(scene)
+    rng = np.random.default_rng(11)
+    org, d = _camera_rays(scenes.default_camera(64, 64), 20000, rng)
+    # plus rays from inside the box towards the teapots, so that boxes are entered from all sides
+    o2 = np.tile([50., 40., 100.], (12000, 1)) + rng.normal(size=(12000, 3)) * [20, 10, 30]
+    tgt = np.array([[20, 5, 120], [60, 5, 120], [20, 5, 60], [60, 5, 60]], dtype=np.float64)[rng.integers(0, 4, 12000)]
+    d2 = tgt + rng.normal(size=(12000, 3)) * 4 - o2
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    org, d = np.concatenate([org, o2]), np.concatenate([d, d2])
+    g, c = gpu.near_collide(org, d, SEED), o.near_collide(org, d, SEED)
+    bez = c["obj"] >= 8
+    assert bez.sum() > 5000
+    same = g["obj"] == c["obj"]
+    assert same[bez].mean() >= 0.99 and same[~bez].mean() >= 0.995      # silhouette rays may converge in one arithmetic only
+    both = bez & same
+    derr = np.abs(g["dist"][both] - c["dist"][both])
+    assert np.median(derr) < 1e-4 and (derr < 1e-3).mean() >= 0.97 and derr.max() < 0.05
+
+
 def _compare_hitpoints(g, c, pos_tol, frac, bezier_objs=()):
     assert len(g) > 0
     kg, kc = _key(g), _key(c)
@@ -163,7 +188,9 @@ def test_eye_pass_hitpoints_teapot(gpu):
     g, c = gpu.hitpoints(), o.hitpoints()
     ok = _compare_hitpoints(g, c, 1e-3, 0.97, bezier_objs=(8,))
     print("teapot hitpoints within 1e-3:", ok)
-    assert gpu.counters()["newton_calls"] == pytest.approx(o.counters()["newton_calls"], rel=0.02)
+    # the oracle solves every patch whose box the ray enters (Bezier.h:248-260); the GPU solves them nearest box
+    # first and skips those that cannot hold a nearer hit, so it counts fewer solves for the same HitPoints
+    assert 0.2 * o.counters()["newton_calls"] <= gpu.counters()["newton_calls"] <= o.counters()["newton_calls"]
 
 
 def _image_parity(g, c, frac=0.995, linf=1e-3, mae=1e-4):
