@@ -202,6 +202,10 @@ struct TraceParams {
     // eye pass
     double pos[3], dir[3], du[3], dv[3];
     int w, h;
+    // Work item k of the eye pass is pixel (k * pix_mul) mod (w * h), pix_mul coprime to w * h: a wave's 64
+    // pixels are spread over the image, so the rays that meet a Bezier object are a few lanes of every wave
+    // (as photons are) instead of all lanes of a few waves, and can be solved in place without idling the rest.
+    unsigned long long pix_mul;
     RawHit* hits; unsigned long long* n_hits; unsigned long long hit_cap;   // n_hits: claimed slots
     unsigned long long* n_real_hits;                                          // HitPoints written
     // photon pass
@@ -307,7 +311,8 @@ __global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneP
                         tfirst = r.task_first; tcount = r.task_count;
                     }
                 } else {
-                    const unsigned long long g = tp.fresh_first + (my - n_resume);
+                    unsigned long long g = tp.fresh_first + (my - n_resume);
+                    if (MODE == MODE_EYE) g = (g * tp.pix_mul) % ((unsigned long long)tp.w * (unsigned long long)tp.h);   // see TraceParams::pix_mul
                     id = (uint32_t)g; dep = 0; node = 0;
                     if (MODE == MODE_EYE) {
                         const int row = (int)(g / (unsigned long long)tp.w), col = (int)(g % (unsigned long long)tp.w);
@@ -976,6 +981,7 @@ struct sppm_ctx {
     uint64_t coop_threshold = 4096;   // rounds with fewer parked rays finish inside the trace kernel
     bool force_coop = false;
     bool photon_coop = true;
+    bool eye_scatter = true;              // eye work items visit the pixels in a scattered order (TraceParams::pix_mul)
     int newton_blocks_per_cu = 8;
     int gather_blocks_per_cu = 4;
     int scatter_blocks_per_cu = 32;
@@ -1091,6 +1097,7 @@ int sppm_create(sppm_ctx** out, int device_id) {
     }
     if (const char* b = getenv("SPPM_COOP_THRESHOLD")) ctx->coop_threshold = (uint64_t)std::max(0ll, atoll(b));
     if (const char* b = getenv("SPPM_FORCE_COOP")) ctx->force_coop = atoi(b) != 0;
+    if (const char* b = getenv("SPPM_EYE_SCATTER")) ctx->eye_scatter = atoi(b) != 0;
     if (const char* b = getenv("SPPM_PHOTON_COOP")) ctx->photon_coop = atoi(b) != 0;
     if (const char* b = getenv("SPPM_GATHER_BPC")) ctx->gather_blocks_per_cu = std::max(1, atoi(b));
     if (const char* b = getenv("SPPM_SCATTER_BPC")) ctx->scatter_blocks_per_cu = std::max(1, atoi(b));
@@ -1279,6 +1286,14 @@ static int launch_scan(sppm_ctx* ctx, const uint32_t* cnt, uint32_t* start, uint
 // queue scalars of the control block
 enum { SC_HITS = 0, SC_DEP = 1, SC_NEXT0 = 2 /* .. SC_NEXT0 + 3 */, SC_PARK0 = 6, SC_TASK0 = 7, SC_PARK1 = 8, SC_TASK1 = 9, SC_REAL_HITS = 10 };
 
+// Smallest m >= want (>= 1) with gcd(m, n) = 1.
+static uint64_t coprime_near(uint64_t n, uint64_t want) {
+    auto gcd = [](uint64_t a, uint64_t b) { while (b) { uint64_t t = a % b; a = b; b = t; } return a; };
+    uint64_t m = std::max<uint64_t>(1, want);
+    while (gcd(m, n) != 1) m++;
+    return m;
+}
+
 static int trace_max_blocks(const sppm_ctx* ctx) { return ctx->num_cu * 4; }
 // output slots that can be left unused in open chunks (one chunk per wave slot of the largest trace grid)
 static uint64_t dep_slack(const sppm_ctx* ctx) { return (uint64_t)trace_max_blocks(ctx) * 4u * TRACE_SLOT_CHUNK; }
@@ -1376,10 +1391,12 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
         return SPPM_OK;
     };
     tp.park_cap = park_cap; tp.task_cap = task_cap;
-    // Eye rays that meet a Bezier object are neighbours in the image, so whole waves would stall in the
-    // in-wave solve while others idle: they are parked and solved by k_newton.  Photons meet it at random,
-    // a few lanes per wave: solving in place costs less than the extra launches of a park round.
-    const bool first_coop = ctx->force_coop || (mode == MODE_PHOTON && ctx->photon_coop);
+    // Photons meet a Bezier object at random, a few lanes per wave, and so do eye rays once the pixels are
+    // dealt to the waves in a scattered order (TraceParams::pix_mul): solving in place costs less than the
+    // extra launches of a park round.  With pixels in row order the rays that meet the object are whole
+    // waves, which would serialise 64 solves each while the other waves idle: then they are parked and
+    // solved by k_newton (SPPM_EYE_SCATTER=0, or SPPM_PHOTON_COOP=0 for photons).
+    const bool first_coop = ctx->force_coop || (mode == MODE_PHOTON && ctx->photon_coop) || (mode == MODE_EYE && ctx->eye_scatter);
     const bool legacy = (mode == MODE_PHOTON && !first_coop);   // photons with parked solves: every round looks at the counters
     if (int rc = set_round(0, true)) return rc;
     if (int rc = launch_trace_mode(ctx, mode, first_coop, blocks_for(fresh_count), tp)) return rc;
@@ -1436,6 +1453,7 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
         TraceParams tp{};
         for (int k = 0; k < 3; k++) { tp.pos[k] = cam->pos[k]; tp.dir[k] = cam->dir[k]; tp.du[k] = cam->du[k]; tp.dv[k] = cam->dv[k]; }
         tp.w = cam->w; tp.h = cam->h;
+        tp.pix_mul = ctx->eye_scatter ? coprime_near(npx, (uint64_t)((double)npx * 0.6180339887)) : 1;
         tp.hits = ctx->raw.p; tp.n_hits = ctx->scalars() + SC_HITS; tp.hit_cap = hit_cap;
         tp.n_real_hits = ctx->scalars() + SC_REAL_HITS;
         tp.counters = ctx->counters.p;
