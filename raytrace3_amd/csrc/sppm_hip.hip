@@ -732,7 +732,7 @@ __device__ __forceinline__ float wave_total_f(float v) {
     return bcast_f(v, 63);
 }
 
-// One tile = 64 consecutive grid-sorted HitPoints, one per lane.
+// One tile = GATHER_TILE consecutive grid-sorted HitPoints, one per lane of the first GATHER_TILE lanes.
 __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
                                             const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, const uint32_t n_hp,
                                             const uint32_t* __restrict__ dstart, const Deposit* __restrict__ deps,
@@ -818,12 +818,17 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
                         const double d2 = vx * vx + vy * vy + vz * vz;
                         const bool c = d2 < SPPM_INIT_R2;      // flann radiusSearch(radius = searchR2): strict '<' on the squared distance
                         const float dn = nx * bnx[r] + ny * bny[r] + nz * bnz[r];
-                        const bool ok = c & (dn > 1e-3f) & (d2 <= R2);
-                        cand += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(c));
-                        pn += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ok));
-                        pr = ok ? fmaf(wr, bfr[r], pr) : pr;
-                        pg = ok ? fmaf(wg, bfg[r], pg) : pg;
-                        pb = ok ? fmaf(wb, bfb[r], pb) : pb;
+                        const bool facing = dn > 1e-3f, inr = d2 <= R2;
+                        const bool ok = c & facing & inr;
+                        // ballots of the bare compares, combined as scalars (a ballot of their conjunction costs two more vector instructions)
+                        const uint64_t cm = __builtin_amdgcn_ballot_w64(c);
+                        cand += (uint32_t)__popcll(cm);
+                        pn += (uint32_t)__popcll(cm & __builtin_amdgcn_ballot_w64(facing) & __builtin_amdgcn_ballot_w64(inr));
+                        if (ok) {   // three FMAs under the lane mask (no per-channel select)
+                            pr = fmaf(wr, bfr[r], pr);
+                            pg = fmaf(wg, bfg[r], pg);
+                            pb = fmaf(wb, bfb[r], pb);
+                        }
                     }
                 }
                 if (pn) {
