@@ -1,5 +1,5 @@
 #!/bin/bash
-# scratch/ab_cfg.sh <config> "ENV=.." ... : bench one config under different environments
+# tools/ab_cfg.sh <config> "ENV=.." ... : bench one config under different environments
 CFG=$1; shift
 for E in "$@"; do
   echo "== $CFG $E"
