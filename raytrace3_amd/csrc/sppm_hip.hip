@@ -989,6 +989,7 @@ struct sppm_ctx {
     bool eye_scatter = true;              // eye work items visit the pixels in a scattered order (TraceParams::pix_mul)
     int newton_blocks_per_cu = 8;
     int gather_blocks_per_cu = 4;
+    int eye_blocks_per_cu = 0;            // 0: as many trace workgroups as the pixels allow (up to 4 per CU)
     int scatter_blocks_per_cu = 32;
     bool verbose = false;
     DevBuf<uint32_t> bucket_of, hstart;
@@ -1106,6 +1107,7 @@ int sppm_create(sppm_ctx** out, int device_id) {
     if (const char* b = getenv("SPPM_PHOTON_COOP")) ctx->photon_coop = atoi(b) != 0;
     if (const char* b = getenv("SPPM_GATHER_BPC")) ctx->gather_blocks_per_cu = std::max(1, atoi(b));
     if (const char* b = getenv("SPPM_SCATTER_BPC")) ctx->scatter_blocks_per_cu = std::max(1, atoi(b));
+    if (const char* b = getenv("SPPM_EYE_BPC")) ctx->eye_blocks_per_cu = std::max(0, atoi(b));
     if (const char* b = getenv("SPPM_NEWTON_BPC")) ctx->newton_blocks_per_cu = std::max(1, atoi(b));
     if (const char* b = getenv("SPPM_VERBOSE")) ctx->verbose = atoi(b) != 0;
     if (ctx->ctl.reserve(ctx->ctl_words()) != hipSuccess || ctx->counters.reserve(1) != hipSuccess) {
@@ -1404,7 +1406,9 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
     const bool first_coop = ctx->force_coop || (mode == MODE_PHOTON && ctx->photon_coop) || (mode == MODE_EYE && ctx->eye_scatter);
     const bool legacy = (mode == MODE_PHOTON && !first_coop);   // photons with parked solves: every round looks at the counters
     if (int rc = set_round(0, true)) return rc;
-    if (int rc = launch_trace_mode(ctx, mode, first_coop, blocks_for(fresh_count), tp)) return rc;
+    int first_blocks = blocks_for(fresh_count);
+    if (mode == MODE_EYE && ctx->eye_blocks_per_cu > 0) first_blocks = std::min(first_blocks, ctx->num_cu * ctx->eye_blocks_per_cu);
+    if (int rc = launch_trace_mode(ctx, mode, first_coop, first_blocks, tp)) return rc;
     int cur = 0;   // queue written by the last launch
     if (!legacy) {
         if (!first_coop) {
