@@ -45,5 +45,9 @@ def sharded_iteration(ctx, cam, seed, replica, total_rounds, per_round, n_lights
         ctx.photon_pass(total_rounds, per_round, seed, replica, photon_begin=total, photon_count=1)
     if pic_tensor is not None:
         ctx.resolve_device(pic_tensor.data_ptr())
+        if world > 1:
+            # the resolve runs on the library's stream, the collective on torch's: finish the former first
+            # (and surface a queue overflow of the queued passes) instead of relying on implicit stream ordering
+            ctx.synchronize()
         return all_reduce_image(pic_tensor)
     return ctx.resolve()
