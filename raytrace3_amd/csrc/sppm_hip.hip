@@ -733,10 +733,24 @@ __device__ __forceinline__ float wave_total_f(float v) {
 }
 
 // One tile = GATHER_TILE consecutive grid-sorted HitPoints, one per lane of the first GATHER_TILE lanes.
+// A cell whose neighbourhood holds very many deposits (a caustic focus) would keep one wave busy long after
+// the others have finished: the wave that owns the cell's HitPoints sweeps only the first GATHER_SPLIT_ROWS rows
+// itself and queues the rest as pieces of GATHER_SPLIT_ROWS rows.  k_gather_split, launched behind k_gather,
+// spreads the pieces over all waves (PIECE = true: one cell of the tile, rows [row_begin, row_end), sums
+// added to the HitPoints with atomics; the owners' plain read-modify-write is over by then).
+#ifndef GATHER_SPLIT_ROWS
+#define GATHER_SPLIT_ROWS 24u
+#endif
+static_assert(GATHER_SPLIT_ROWS % GATHER_ROWS == 0, "a sweep is cut between passes of GATHER_ROWS rows");
+struct GatherPiece { uint32_t tile_base, lead, row_begin, row_end; };   // lead: lane of one HitPoint of the cell in its tile
+
+template <bool PIECE>
 __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
                                             const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, const uint32_t n_hp,
                                             const uint32_t* __restrict__ dstart, const Deposit* __restrict__ deps,
-                                            const GridParams g, uint32_t& cand, uint32_t& acc_n) {
+                                            const GridParams g, GatherPiece* __restrict__ pieces, unsigned long long* n_pieces,
+                                            const uint32_t piece_cap, unsigned int* overflow, const GatherPiece piece,
+                                            uint32_t& cand, uint32_t& acc_n) {
     const int lane = lane_id();
     const uint32_t mine = base + lane;
     const bool valid = (uint32_t)lane < GATHER_TILE && mine < n_hp;
@@ -746,6 +760,7 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
     float tr = 0, tg = 0, tb = 0;
     uint32_t tn = 0;
     uint64_t todo = __ballot(valid);
+    if (PIECE) todo &= 1ull << (piece.lead & 63u);               // only the cell the piece belongs to
     while (todo) {
         const int lead = __ffsll((unsigned long long)todo) - 1;
         const uint64_t key = bcast_u64(mp.key, lead);
@@ -766,6 +781,19 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
         uint32_t F = 0;                     // flat offset of the next row
         uint32_t cur_end = 0, cur_base = 0; // current range: flat end, (deposit index - flat index)
         uint32_t cur_klo = 0, cur_khi = 0;  // its cell key
+        uint32_t F_limit = GATHER_SPLIT_ROWS * 64u;   // this sweep stops here
+        if (PIECE) {
+            F = piece.row_begin * 64u; F_limit = piece.row_end * 64u;
+            while (cur_end <= F && cells) {           // walk to the range that holds the first entry wanted
+                const int k = __ffsll((unsigned long long)cells) - 1;
+                cells &= cells - 1;
+                const uint32_t start = cur_end;
+                cur_base = bcast_u(nb_s, k) - start;
+                cur_end = start + bcast_u(nb_len, k);
+                cur_klo = bcast_u((uint32_t)nb_key, k);
+                cur_khi = bcast_u((uint32_t)(nb_key >> 32), k);
+            }
+        }
         while (cells || F < cur_end) {
             double ax[GATHER_ROWS], ay[GATHER_ROWS], az[GATHER_ROWS];
             float bnx[GATHER_ROWS], bny[GATHER_ROWS], bnz[GATHER_ROWS], bfr[GATHER_ROWS], bfg[GATHER_ROWS], bfb[GATHER_ROWS];
@@ -837,13 +865,38 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
                     acc_n += pn;
                 }
             }
+            if (F >= F_limit) break;   // checked once per pass: GATHER_SPLIT_ROWS is a multiple of GATHER_ROWS
+        }
+        if (!PIECE && (cells || F < cur_end)) {   // rows are left: queue them in pieces
+            uint32_t left = cur_end - F;           // entries left in the current range ...
+            for (uint64_t q = cells; q; q &= q - 1) left += bcast_u(nb_len, __ffsll((unsigned long long)q) - 1);   // ... and in those not yet opened
+            const uint32_t n_p = (left + GATHER_SPLIT_ROWS * 64u - 1u) / (GATHER_SPLIT_ROWS * 64u);
+            unsigned long long first = 0;
+            if (lane == 0) first = atomicAdd(n_pieces, (unsigned long long)n_p);
+            first = bcast_u64(first, 0);
+            if (first + n_p <= piece_cap) {
+                for (uint32_t i = lane; i < n_p; i += 64) {
+                    GatherPiece pc;
+                    pc.tile_base = base; pc.lead = (uint32_t)lead;
+                    pc.row_begin = (i + 1u) * GATHER_SPLIT_ROWS; pc.row_end = (i + 2u) * GATHER_SPLIT_ROWS;
+                    pieces[first + i] = pc;
+                }
+            } else {
+                atomicOr(overflow, 8u);             // the piece queue is sized for 2^20 pieces of 6144 deposits: report, do not drop silently
+            }
         }
     }
     if (valid && tn) {
-        float4 t = hp_tao[mine];
-        t.x += tr; t.y += tg; t.z += tb;
-        t.w = __int_as_float(__float_as_int(t.w) + (int)tn);
-        hp_tao[mine] = t;
+        if (PIECE) {
+            float* t = (float*)&hp_tao[mine];
+            atomicAdd(t + 0, tr); atomicAdd(t + 1, tg); atomicAdd(t + 2, tb);
+            atomicAdd((int*)(t + 3), (int)tn);
+        } else {
+            float4 t = hp_tao[mine];
+            t.x += tr; t.y += tg; t.z += tb;
+            t.w = __int_as_float(__float_as_int(t.w) + (int)tn);
+            hp_tao[mine] = t;
+        }
     }
 }
 
@@ -854,7 +907,8 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
 __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
                                                 const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
                                                 const uint32_t* __restrict__ dstart, const Deposit* __restrict__ deps,
-                                                GridParams g, uint32_t* tile_ctr, DevCounters* counters) {
+                                                GridParams g, uint32_t* tile_ctr, GatherPiece* __restrict__ pieces,
+                                                unsigned long long* n_pieces, uint32_t piece_cap, DevCounters* counters) {
     const uint32_t n_tiles = (n_hp + GATHER_TILE - 1u) / GATHER_TILE;
     const uint32_t per = (n_tiles + 7u) >> 3;
     uint32_t cand = 0, acc_n = 0;   // wave-uniform tallies
@@ -866,8 +920,34 @@ __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_po
             if (lane_id() == 0) t = atomicAdd(&tile_ctr[q * 16], 1u);
             t = bcast_u(t, 0) + q * per;
             if (t >= q_end) break;
-            gather_tile(t * GATHER_TILE, hp_pos, hp_nr, hp_wgt, hp_tao, n_hp, dstart, deps, g, cand, acc_n);
+            gather_tile<false>(t * GATHER_TILE, hp_pos, hp_nr, hp_wgt, hp_tao, n_hp, dstart, deps, g, pieces, n_pieces, piece_cap,
+                               &counters->overflow, GatherPiece{0, 0, 0, 0}, cand, acc_n);
         }
+    }
+    if (lane_id() == 0) {
+        if (cand) atomicAdd(&counters->candidates, (unsigned long long)cand);
+        if (acc_n) atomicAdd(&counters->accepted, (unsigned long long)acc_n);
+    }
+}
+
+// The queued pieces of heavy cells (see GATHER_SPLIT_ROWS), one wave per piece at a time.
+__global__ void __launch_bounds__(256) k_gather_split(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
+                                                      const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
+                                                      const uint32_t* __restrict__ dstart, const Deposit* __restrict__ deps, GridParams g,
+                                                      const GatherPiece* __restrict__ pieces, const unsigned long long* __restrict__ n_pieces,
+                                                      uint32_t piece_cap, unsigned long long* next_piece, DevCounters* counters) {
+    const unsigned long long n = min(*n_pieces, (unsigned long long)piece_cap);
+    const unsigned long long n_waves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    uint32_t cand = 0, acc_n = 0;
+    // wave w starts with piece w; only when there are more pieces than waves does the shared counter come into
+    // play (a launch with nothing queued costs no atomic at all)
+    for (unsigned long long i = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n;) {
+        const GatherPiece pc = pieces[i];
+        gather_tile<true>(pc.tile_base, hp_pos, hp_nr, hp_wgt, hp_tao, n_hp, dstart, deps, g, nullptr, nullptr, 0u, nullptr, pc, cand, acc_n);
+        if (n <= n_waves) break;
+        unsigned long long nx = 0;
+        if (lane_id() == 0) nx = atomicAdd(next_piece, 1ull);
+        i = n_waves + bcast_u64(nx, 0);
     }
     if (lane_id() == 0) {
         if (cand) atomicAdd(&counters->candidates, (unsigned long long)cand);
@@ -1003,6 +1083,7 @@ struct sppm_ctx {
     GridParams grid{};
     // photon pass
     DevBuf<Deposit> dep, sdep;   // deposits of a batch as traced / sorted by bucket
+    DevBuf<GatherPiece> pieces;  // queued row ranges of heavy cells (k_gather -> k_gather_split)
     DevBuf<uint32_t> dstart, scan_partial;
     // Control block, one allocation so that one memset resets a pass: queue scalars (CTL_SCALARS x u64) |
     // gather tile counters (8 x 16 u32, 64 B apart) | {next, end} of the open output chunk of every trace wave slot
@@ -1130,7 +1211,7 @@ void sppm_destroy(sppm_ctx* ctx) {
     ctx->raw.release(); ctx->park[0].release(); ctx->park[1].release(); ctx->ntask[0].release(); ctx->ntask[1].release(); ctx->nres.release();
     ctx->bucket_of.release(); ctx->hist.release(); ctx->hstart.release();
     ctx->hp_pos.release(); ctx->hp_nr.release(); ctx->hp_wgt.release(); ctx->hp_tao.release(); ctx->hp_meta.release();
-    ctx->dep.release(); ctx->sdep.release();
+    ctx->dep.release(); ctx->sdep.release(); ctx->pieces.release();
     ctx->dstart.release(); ctx->scan_partial.release(); ctx->ctl.release(); ctx->counters.release(); ctx->pic.release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1291,7 +1372,8 @@ static int launch_scan(sppm_ctx* ctx, const uint32_t* cnt, uint32_t* start, uint
 }  // extern "C" (templates below need C++ linkage)
 
 // queue scalars of the control block
-enum { SC_HITS = 0, SC_DEP = 1, SC_NEXT0 = 2 /* .. SC_NEXT0 + 3 */, SC_PARK0 = 6, SC_TASK0 = 7, SC_PARK1 = 8, SC_TASK1 = 9, SC_REAL_HITS = 10 };
+enum { SC_HITS = 0, SC_DEP = 1, SC_NEXT0 = 2 /* .. SC_NEXT0 + 3 */, SC_PARK0 = 6, SC_TASK0 = 7, SC_PARK1 = 8, SC_TASK1 = 9, SC_REAL_HITS = 10,
+       SC_PIECES = 11, SC_NEXT_PIECE = 12 };
 
 // Smallest m >= want (>= 1) with gcd(m, n) = 1.
 static uint64_t coprime_near(uint64_t n, uint64_t want) {
@@ -1348,7 +1430,7 @@ static int read_queues(sppm_ctx* ctx, QueueState& q) {
 static int overflow_code(sppm_ctx* ctx, const DevCounters& dc) {
     if (dc.overflow == 0) return SPPM_OK;
     (void)hipMemsetAsync(&ctx->counters.p->overflow, 0, sizeof(unsigned int), ctx->stream);   // seen: clear
-    if (dc.overflow & 6u) return fail(ctx, SPPM_E_CAPACITY, "a ray / task / deposit queue overflowed");
+    if (dc.overflow & 14u) return fail(ctx, SPPM_E_CAPACITY, "a ray / task / deposit / gather-piece queue overflowed");
     return SPPM_RETRY_HITS;   // HitPoint buffer too small: the eye pass retries with more room
 }
 
@@ -1584,8 +1666,14 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
             tic(ctx, PH_GATHER);
             const uint64_t tiles = (ctx->n_hp + GATHER_TILE - 1) / GATHER_TILE;
             const int blocks = (int)std::max<uint64_t>(8, std::min<uint64_t>((uint64_t)ctx->num_cu * ctx->gather_blocks_per_cu, ((tiles + 3) / 4 + 7) / 8 * 8));
+            const uint32_t piece_cap = 1u << 20;
+            HIPCHK(ctx->pieces.reserve(piece_cap));
             hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->hp_tao.p,
-                               (uint32_t)ctx->n_hp, ctx->dstart.p, ctx->sdep.p, ctx->grid, ctx->tile_ctr(), ctx->counters.p);
+                               (uint32_t)ctx->n_hp, ctx->dstart.p, ctx->sdep.p, ctx->grid, ctx->tile_ctr(), ctx->pieces.p,
+                               ctx->scalars() + SC_PIECES, piece_cap, ctx->counters.p);
+            hipLaunchKernelGGL(k_gather_split, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p,
+                               ctx->hp_tao.p, (uint32_t)ctx->n_hp, ctx->dstart.p, ctx->sdep.p, ctx->grid, ctx->pieces.p,
+                               ctx->scalars() + SC_PIECES, piece_cap, ctx->scalars() + SC_NEXT_PIECE, ctx->counters.p);
             HIPCHK(hipGetLastError());
             toc(ctx);
             ctx->gather_launches++;
@@ -1666,6 +1754,11 @@ int sppm_get_counters(sppm_ctx* ctx, sppm_counters* out) {
     out->photons = dc.photons; out->segments = dc.segments; out->deposits = dc.deposits;
     out->candidates = dc.candidates; out->accepted = dc.accepted; out->hitpoints = ctx->n_hp;
     out->newton_calls = dc.newton_calls; out->eye_segments = dc.eye_segments;
+    if (ctx->verbose) {
+        unsigned long long np = 0;
+        (void)hipMemcpy(&np, ctx->scalars() + SC_PIECES, sizeof(np), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[sppm] gather pieces queued in the last batch: %llu\n", np);
+    }
     if (ctx->verbose && dc.stamps[0])
         fprintf(stderr, "[sppm] trace loop cycles: refill %llu analytic %llu bezier %llu merge/park %llu finish %llu bounce %llu loop %llu\n",
                 dc.stamps[0], dc.stamps[1], dc.stamps[2], dc.stamps[3], dc.stamps[4], dc.stamps[5], dc.stamps[7]);
