@@ -185,7 +185,10 @@ enum { MODE_EYE = 0, MODE_PHOTON = 1 };
 #endif
 // work items a wave claims per atomic on the work counter
 #define TRACE_WORK_CHUNK (MODE == MODE_EYE ? TRACE_WORK_CHUNK_EYE : 128u)
-#define TRACE_SLOT_CHUNK 256u     // deposit slots a wave claims per atomic on the deposit counter
+// output slots (deposits / raw HitPoints) a wave claims per atomic on the slot counter
+#ifndef TRACE_SLOT_CHUNK
+#define TRACE_SLOT_CHUNK 256u
+#endif
 #define DEP_HOLE 0x00ffffffu      // DepB::bucket of a claimed but unused slot (buckets are < 2^22)
 
 struct TraceParams {
@@ -1069,6 +1072,7 @@ struct sppm_ctx {
     bool eye_scatter = true;              // eye work items visit the pixels in a scattered order (TraceParams::pix_mul)
     int newton_blocks_per_cu = 8;
     int gather_blocks_per_cu = 4;
+    int trace_blocks_per_cu = 0;          // 0: as many trace workgroups per CU as stay resident (2 or 3)
     int eye_blocks_per_cu = 0;            // 0: as many trace workgroups as the pixels allow (up to 4 per CU)
     int scatter_blocks_per_cu = 32;
     bool verbose = false;
@@ -1188,6 +1192,7 @@ int sppm_create(sppm_ctx** out, int device_id) {
     if (const char* b = getenv("SPPM_PHOTON_COOP")) ctx->photon_coop = atoi(b) != 0;
     if (const char* b = getenv("SPPM_GATHER_BPC")) ctx->gather_blocks_per_cu = std::max(1, atoi(b));
     if (const char* b = getenv("SPPM_SCATTER_BPC")) ctx->scatter_blocks_per_cu = std::max(1, atoi(b));
+    if (const char* b = getenv("SPPM_TRACE_BPC")) ctx->trace_blocks_per_cu = std::max(0, atoi(b));
     if (const char* b = getenv("SPPM_EYE_BPC")) ctx->eye_blocks_per_cu = std::max(0, atoi(b));
     if (const char* b = getenv("SPPM_NEWTON_BPC")) ctx->newton_blocks_per_cu = std::max(1, atoi(b));
     if (const char* b = getenv("SPPM_VERBOSE")) ctx->verbose = atoi(b) != 0;
@@ -1454,7 +1459,12 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
     HIPCHK(ctx->nres.reserve(task_cap));
     unsigned long long* sc = ctx->scalars();
     const int max_blocks = trace_max_blocks(ctx);
-    auto blocks_for = [&](uint64_t items) { return (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)max_blocks, (items + 255) / 256)); };
+    // persistent workgroups: as many as stay resident (2 per CU with in-wave solves, 3 without), not more
+    auto blocks_for = [&](uint64_t items, bool coop) {
+        const int per_cu = ctx->trace_blocks_per_cu > 0 ? ctx->trace_blocks_per_cu : (coop ? 2 : 3);
+        const uint64_t cap = std::min<uint64_t>((uint64_t)max_blocks, (uint64_t)ctx->num_cu * per_cu);
+        return (int)std::max<uint64_t>(1, std::min<uint64_t>(cap, (items + 255) / 256));
+    };
     auto park_ctr = [&](int i) { return sc + (i ? SC_PARK1 : SC_PARK0); };
     auto task_ctr = [&](int i) { return sc + (i ? SC_TASK1 : SC_TASK0); };
     int next_slot = 0;   // work counters SC_NEXT0.. are zero after the reset; later launches clear theirs first
@@ -1488,7 +1498,7 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
     const bool first_coop = ctx->force_coop || (mode == MODE_PHOTON && ctx->photon_coop) || (mode == MODE_EYE && ctx->eye_scatter);
     const bool legacy = (mode == MODE_PHOTON && !first_coop);   // photons with parked solves: every round looks at the counters
     if (int rc = set_round(0, true)) return rc;
-    int first_blocks = blocks_for(fresh_count);
+    int first_blocks = blocks_for(fresh_count, first_coop);
     if (mode == MODE_EYE && ctx->eye_blocks_per_cu > 0) first_blocks = std::min(first_blocks, ctx->num_cu * ctx->eye_blocks_per_cu);
     if (int rc = launch_trace_mode(ctx, mode, first_coop, first_blocks, tp)) return rc;
     int cur = 0;   // queue written by the last launch
@@ -1497,7 +1507,7 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
             if (int rc = launch_newton(0)) return rc;
             if (int rc = set_round(0, false)) return rc;
             // the count is unknown here: a generous grid, of which the workgroups beyond the work leave at once
-            if (int rc = launch_trace_mode(ctx, mode, true, std::max(1, blocks_for(fresh_count) / 2), tp)) return rc;
+            if (int rc = launch_trace_mode(ctx, mode, true, std::max(1, blocks_for(fresh_count, true) / 2), tp)) return rc;
             cur = 1;
         }
         const bool may_queue = (mode == MODE_EYE && has_dual_lobe);
@@ -1516,7 +1526,7 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
         HIPCHK(hipMemsetAsync(task_ctr(nxt), 0, sizeof(unsigned long long), ctx->stream));
         if (int rc = set_round(cur, false)) return rc;
         const bool coop = !legacy || ctx->force_coop || n_park < ctx->coop_threshold;
-        if (int rc = launch_trace_mode(ctx, mode, coop, blocks_for(n_park), tp)) return rc;
+        if (int rc = launch_trace_mode(ctx, mode, coop, blocks_for(n_park, coop), tp)) return rc;
         cur = nxt;
     }
     return fail(ctx, SPPM_E_DEVICE, "trace rounds did not drain");
