@@ -74,8 +74,29 @@ def cpu_baseline(scene, w, h, rounds, threads):
     }
 
 
+VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9      # CUs x SIMDs x lanes per cycle x 2.4 GHz: vector instructions per lane per second
+
+
+def measured_valu():
+    """Vector instructions per launch of the two dominant kernels from the committed PMC profile
+    (SQ_INSTS_VALU, wave instructions): both kernels live on VALU issue, not on HBM."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+            g, t = d.get("k_gather", {}).get("SQ_INSTS_VALU"), d.get("k_trace<1, true>", {}).get("SQ_INSTS_VALU")
+            if g and t:
+                g += d.get("k_gather_split", {}).get("SQ_INSTS_VALU") or 0.0
+                best = {"k_gather_wave_insts": float(g), "k_trace_photon_wave_insts": float(t), "source": "profiles/" + os.path.basename(f)}
+        except (OSError, ValueError):
+            pass
+    return best
+
+
 def measured_traffic():
-    """HBM bytes per k_gather launch from the rocprofv3 PMC passes committed under profiles/
+    """HBM bytes per gather (k_gather and k_gather_split) from the rocprofv3 PMC passes committed under profiles/
     ((2 * FETCH_SIZE + WRITE_SIZE) * 1024, collected by tools/gpu_profile.sh on this same command);
     None when no such profile is in the tree."""
     import glob
@@ -85,8 +106,9 @@ def measured_traffic():
             with open(f) as fh:
                 d = json.load(fh)
             t = d.get("k_gather", {}).get("hbm_traffic_bytes_per_launch")
-            if t:
-                best = (float(t), os.path.basename(f))
+            if t:      # the heavy-cell pieces are part of the same gather
+                t2 = d.get("k_gather_split", {}).get("hbm_traffic_bytes_per_launch") or 0.0
+                best = (float(t) + float(t2), os.path.basename(f))
         except (OSError, ValueError):
             pass
     return best
@@ -188,7 +210,7 @@ def main():
             "photon_pass_mphotons_per_s": per_rank * args.steps / pass_s / 1e6 if pass_s > 0 else None,
             "kernel_ms_per_step": {k: v / args.steps for k, v in acc.items()},
             "counters_per_step": {k: (v / args.steps if k != "hitpoints" else v) for k, v in counters.items()},
-            "roofline": {"kernel": "k_gather", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "k_gather + k_gather_split (the gather of one photon pass)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                          "traffic_source": ("profiles/" + traffic[1] + ": (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc")
                          if traffic else None,
@@ -197,6 +219,15 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_model / max(1, gather_launches),
                          "avg_launch_ms": acc["gather_ms"] / max(1, gather_launches)},
         }
+        valu = measured_valu()
+        if valu:
+            gl = max(1, gather_launches)
+            valu["k_gather_frac_of_valu_peak"] = valu["k_gather_wave_insts"] * 64 / (acc["gather_ms"] / gl / 1e3) / VALU_PEAK_LANE_OPS
+            valu["k_trace_photon_frac_of_valu_peak"] = (valu["k_trace_photon_wave_insts"] * 64 /
+                                                        (acc["photon_trace_ms"] / gl / 1e3) / VALU_PEAK_LANE_OPS)
+            valu["note"] = ("wave instructions x 64 lanes / HIP-event duration / (256 CU x 4 SIMD x 16 lanes x 2.4 GHz); durations "
+                            "include the neighbour stream when inflight > 1")
+            out["valu"] = valu
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, w, h, args.cpu_rounds, 4)
         print(json.dumps(out), flush=True)
