@@ -189,19 +189,42 @@ int sppm_resolve(sppm_ctx* ctx, double* pic_hw3, int accumulate);
  * collective (RCCL all-reduce of the flux image) can run on it in place. */
 int sppm_resolve_device(sppm_ctx* ctx, float* dev_pic_hw3);
 
-/* sppm_photon_pass and sppm_resolve_device only QUEUE their kernels on the context's stream
+/* The image sum and its tone-mapped copy, SPPMRayTracer::render (raytracer/Raytracer.h:449-470), kept on
+ * the GPU: a film is the fp64 `camera.pic` of that loop, [h][w][3], zero when created. */
+typedef struct sppm_film sppm_film;
+int sppm_film_create(sppm_film** out, int device_id, int w, int h);
+void sppm_film_destroy(sppm_film* film);
+const char* sppm_film_last_error(const sppm_film* film);
+int sppm_film_clear(sppm_film* film);
+
+/* film += resolve of the context's last photon pass (Raytracer.h:281-293 into :449-458), queued on the
+ * context's stream; context and film must be on the same GPU and of the same resolution.  Several
+ * contexts may add to one film, each from its own host thread. */
+int sppm_film_add(sppm_ctx* ctx, sppm_film* film);
+
+/* out[h - 1 - i][j][c] = toInt(film[i][j][k] / n_images) with c = k (rgb = 0: the cv::Mat the reference
+ * passes to cv::imwrite, Raytracer.h:460-470, toInt of :11-13) or c = 2 - k (rgb = 1: the same picture
+ * with the channels in PPM order).  Waits for every add queued before the call.  Bytes are those the
+ * host's exp / pow give: elements the device library could round the other way are recomputed on the host. */
+int sppm_film_tonemap(sppm_film* film, double n_images, int rgb, uint8_t* out_hw3);
+
+/* The fp64 sum itself, out of and into the film (a checkpoint of the running mean and its resume). */
+int sppm_film_read(sppm_film* film, double* pic_hw3);
+int sppm_film_write(sppm_film* film, const double* pic_hw3);
+
+/* sppm_photon_pass, sppm_resolve_device and sppm_film_add only QUEUE their kernels on the context's stream
  * (the reference is synchronous; a GPU host wants to keep queueing).  sppm_synchronize waits
  * for everything queued and returns the error, if any, that a queued pass ran into (a ray /
  * task / deposit queue overflow: SPPM_E_CAPACITY).  sppm_resolve, sppm_get_counters and the
  * next sppm_eye_pass report such an error as well.  No counterpart in the reference. */
 int sppm_synchronize(sppm_ctx* ctx);
 
-/* Copy out up to cap HitPoints; *n receives |Hvec|. */
 /* Counters and timings normally restart at every sppm_eye_pass.  accumulate = 1 clears them now and
  * lets them run on over the following passes (a benchmark reads them once after K iterations instead
  * of waiting for the stream after each); accumulate = 0 clears them and restores the default. */
 int sppm_stats_mode(sppm_ctx* ctx, int accumulate);
 
+/* Copy out up to cap HitPoints; *n receives |Hvec|. */
 int sppm_get_hitpoints(sppm_ctx* ctx, sppm_hitpoint* out, uint64_t cap, uint64_t* n);
 int sppm_get_counters(sppm_ctx* ctx, sppm_counters* out);
 int sppm_get_timings(sppm_ctx* ctx, sppm_timings* out);

@@ -929,6 +929,15 @@ void oracle_reflected_unit(const double* I, const double* N, double* out3) { put
 void oracle_rotated(const double* v, const double* axis, double angle, double* out3) { put3(out3, rotated(v3(v), v3(axis), angle)); }
 void oracle_rand_refl(const double* N, double u1, double u2, double* out3) { put3(out3, RandReflFrom(v3(N), u1, u2)); }
 int oracle_to_int(double x) { return int(std::pow(1 - std::exp(-x), 1 / 2.2) * 255 + .5); }  // Raytracer.h:24-26
+// The byte image SPPMRayTracer::render writes (Raytracer.h:460-466): m1.ptr<uchar>(h - 1 - i1)[j * 3 + k] =
+// toInt(pic[i1][j][k] / n_images); rgb != 0 stores channel k at byte 2 - k instead (the same picture as a PPM).
+void oracle_tonemap(const double* pic_hw3, int w, int h, double n_images, int rgb, uint8_t* out_hw3) {
+    for (int i1 = 0; i1 < h; i1++)
+        for (int j = 0; j < w; j++)
+            for (int k = 0; k < 3; k++)
+                out_hw3[((size_t)(h - 1 - i1) * w + j) * 3 + (rgb ? 2 - k : k)] =
+                    (uint8_t)oracle_to_int(pic_hw3[((size_t)i1 * w + j) * 3 + k] / n_images);
+}
 void oracle_hitpoint_update(double* R2, int32_t* N, double* tao3, int32_t* newN) {
     HitPoint h; h.R2 = *R2; h.N = *N; h.tao = v3(tao3); h.newN = *newN;
     h.update();

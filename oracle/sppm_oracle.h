@@ -63,6 +63,7 @@ void oracle_reflected_unit(const double* I, const double* N, double* out3);
 void oracle_rotated(const double* v, const double* axis, double angle, double* out3);
 void oracle_rand_refl(const double* N, double u1, double u2, double* out3);
 int oracle_to_int(double x);
+void oracle_tonemap(const double* pic_hw3, int w, int h, double n_images, int rgb, uint8_t* out_hw3);
 void oracle_hitpoint_update(double* R2, int32_t* N, double* tao3, int32_t* newN);
 void oracle_mwc_kat(int n, uint32_t* out_u32, double* out_uniform01);
 uint32_t oracle_rng_u32(uint64_t seed, uint32_t stream, uint32_t path, uint32_t sub, uint32_t idx);

@@ -5,4 +5,4 @@ C-ABI of include/sppm_abi.h; this package is the Python host side used by the
 tests and bench.py.  Nothing here falls back to a CPU implementation.
 """
 from . import abi, scenes  # noqa: F401
-from .abi import SppmContext, SppmError  # noqa: F401
+from .abi import Film, SppmContext, SppmError  # noqa: F401

@@ -95,6 +95,14 @@ ABI_SYMBOLS = {
     "sppm_photon_pass": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]),
     "sppm_resolve": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
     "sppm_resolve_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sppm_film_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
+    "sppm_film_destroy": (None, [C.c_void_p]),
+    "sppm_film_last_error": (C.c_char_p, [C.c_void_p]),
+    "sppm_film_clear": (C.c_int, [C.c_void_p]),
+    "sppm_film_add": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sppm_film_tonemap": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_void_p]),
+    "sppm_film_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "sppm_film_write": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "sppm_synchronize": (C.c_int, [C.c_void_p]),
     "sppm_stats_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "sppm_get_hitpoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
@@ -240,3 +248,56 @@ class SppmContext:
         self._check(self.lib.sppm_debug_photon_deposits(self._ctx, rounds, per_round, photon_begin, photon_count, seed, replica,
                                                         _dptr(out), cap, C.byref(n)), "sppm_debug_photon_deposits")
         return out[:n.value]
+
+
+class Film:
+    """The device-resident image sum of SPPMRayTracer::render (raytracer/Raytracer.h:449-470):
+    contexts add their resolved images to it, tonemap() gives the bytes the reference writes."""
+
+    def __init__(self, w, h, device=0, lib=None):
+        self.lib = lib or load_library()
+        self.w, self.h = int(w), int(h)
+        self._film = C.c_void_p()
+        rc = self.lib.sppm_film_create(C.byref(self._film), device, self.w, self.h)
+        if rc != 0:
+            self._film = C.c_void_p()
+            raise SppmError(f"sppm_film_create failed (rc={rc})")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise SppmError(f"{what} failed (rc={rc}): {self.lib.sppm_film_last_error(self._film).decode()}")
+
+    def add(self, ctx):
+        """film += the image of ctx's last photon pass (queued on ctx's stream)."""
+        ctx._check(self.lib.sppm_film_add(ctx._ctx, self._film), "sppm_film_add")
+
+    def clear(self):
+        self._check(self.lib.sppm_film_clear(self._film), "sppm_film_clear")
+
+    def read(self):
+        out = np.zeros((self.h, self.w, 3), dtype=np.float64)
+        self._check(self.lib.sppm_film_read(self._film, _dptr(out)), "sppm_film_read")
+        return out
+
+    def write(self, pic):
+        pic = np.ascontiguousarray(pic, dtype=np.float64)
+        if pic.shape != (self.h, self.w, 3):
+            raise ValueError("film image must be [h][w][3]")
+        self._check(self.lib.sppm_film_write(self._film, _dptr(pic)), "sppm_film_write")
+
+    def tonemap(self, n_images, rgb=False):
+        out = np.zeros((self.h, self.w, 3), dtype=np.uint8)
+        self._check(self.lib.sppm_film_tonemap(self._film, float(n_images), int(bool(rgb)), out.ctypes.data_as(C.c_void_p)),
+                    "sppm_film_tonemap")
+        return out
+
+    def close(self):
+        if self._film:
+            self.lib.sppm_film_destroy(self._film)
+            self._film = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -19,6 +19,8 @@
 #include <cstdlib>
 #include <cstddef>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -970,6 +972,40 @@ __global__ void k_resolve(const float4* hp_nr, const float4* hp_wgt, const float
     atomicAdd(&pic[3 * (size_t)pix + 2], (float)(t.z * s));
 }
 
+// ------------------------------------------------------------------ film: image sum and tone-map (Raytracer.h:449-470)
+// film += resolve: the image sum of SPPMRayTracer::render (Raytracer.h:449-458) taken straight from the HitPoints, in fp64
+// as the reference's camera.pic.  Contexts on other streams add to the same film, hence the atomics.
+__global__ void k_film_add(const float4* hp_nr, const float4* hp_wgt, const float4* hp_tao, uint32_t n_hp, double inv_norm, double* film) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_hp) return;
+    float4 t = hp_tao[i];
+    if (t.x == 0.f && t.y == 0.f && t.z == 0.f) return;
+    int pix = __float_as_int(hp_wgt[i].w);
+    double s = inv_norm / (double)hp_nr[i].w;   // 1 / PI / (R2 * cnt * onetime)
+    unsafeAtomicAdd(&film[3 * (size_t)pix + 0], (double)t.x * s);
+    unsafeAtomicAdd(&film[3 * (size_t)pix + 1], (double)t.y * s);
+    unsafeAtomicAdd(&film[3 * (size_t)pix + 2], (double)t.z * s);
+}
+
+// toInt(film / n_images) of Raytracer.h:11-13 into the byte image the reference hands to cv::imwrite (:460-466): rows
+// flipped, channel k at byte k (rgb = 0) or at byte 2 - k (rgb = 1, what a PPM wants).  exp / pow of the device library
+// may differ from the host's in the last place, which matters only when the value sits on a rounding step of the
+// truncation: those elements are listed in `flagged` ([0] = count) and recomputed by the host.
+__global__ void k_tonemap(const double* film, int w, int h, double n_images, int rgb, uint8_t* out, uint32_t* flagged, uint32_t flag_cap) {
+    const size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (e >= (size_t)w * h * 3) return;
+    const int k = (int)(e % 3);
+    const size_t p = e / 3;
+    const int j = (int)(p % (size_t)w), i1 = (int)(p / (size_t)w);
+    const double v = pow(1.0 - exp(-(film[e] / n_images)), 1.0 / 2.2) * 255.0 + 0.5;
+    if (!(fabs(v - rint(v)) >= 1e-6)) {   // also NaN
+        uint32_t s = atomicAdd(&flagged[0], 1u);
+        if (s < flag_cap) flagged[1 + s] = (uint32_t)e;
+    }
+    const int iv = (int)v;
+    out[((size_t)(h - 1 - i1) * w + j) * 3 + (rgb ? 2 - k : k)] = (uint8_t)iv;
+}
+
 __global__ void k_fill_u32(uint32_t* p, size_t n, uint32_t v) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -1901,6 +1937,176 @@ int sppm_debug_newton(sppm_ctx* ctx, uint64_t n, const double* org, const double
     } while (0);
     o.release(); d.release(); r.release(); p.release();
     return rc;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ film (Raytracer.h:449-470)
+#define FILM_FLAG_CAP 4096u
+struct sppm_film {
+    int device = 0, w = 0, h = 0;
+    hipStream_t stream = nullptr;
+    DevBuf<double> acc;
+    DevBuf<uint8_t> bytes;
+    DevBuf<uint32_t> flagged;
+    std::mutex mu;                              // contexts add from their own host threads
+    std::map<sppm_ctx*, hipEvent_t> last_add;   // the latest add queued by each context
+    std::string err;
+    size_t elems() const { return (size_t)w * h * 3; }
+};
+
+static int film_fail(sppm_film* f, int code, const std::string& msg) {
+    if (f) f->err = msg;
+    return code;
+}
+#define FILMCHK(expr)                                                                                                   \
+    do {                                                                                                                \
+        hipError_t e_ = (expr);                                                                                         \
+        if (e_ != hipSuccess) return film_fail(film, SPPM_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// The film's stream waits for every add queued so far.
+static int film_join(sppm_film* film) {
+    for (auto& kv : film->last_add) FILMCHK(hipStreamWaitEvent(film->stream, kv.second, 0));
+    return SPPM_OK;
+}
+
+static inline uint8_t host_to_int(double x) { return (uint8_t)(int)(std::pow(1 - std::exp(-x), 1 / 2.2) * 255 + .5); }
+
+extern "C" {
+
+int sppm_film_create(sppm_film** out, int device_id, int w, int h) {
+    if (!out) return SPPM_E_INVALID;
+    *out = nullptr;
+    if (w <= 0 || h <= 0 || (uint64_t)w * (uint64_t)h * 3 >= (1ull << 32)) return SPPM_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return SPPM_E_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return SPPM_E_DEVICE;
+    sppm_film* film = new (std::nothrow) sppm_film();
+    if (!film) return SPPM_E_NOMEM;
+    film->device = device_id; film->w = w; film->h = h;
+    if (hipStreamCreate(&film->stream) != hipSuccess) { delete film; return SPPM_E_DEVICE; }
+    if (film->acc.reserve(film->elems()) != hipSuccess || film->bytes.reserve(film->elems()) != hipSuccess ||
+        film->flagged.reserve(1 + FILM_FLAG_CAP) != hipSuccess || hipMemset(film->acc.p, 0, film->elems() * sizeof(double)) != hipSuccess) {
+        film->acc.release(); film->bytes.release(); film->flagged.release();
+        (void)hipStreamDestroy(film->stream);
+        delete film;
+        return SPPM_E_NOMEM;
+    }
+    *out = film;
+    return SPPM_OK;
+}
+
+void sppm_film_destroy(sppm_film* film) {
+    if (!film) return;
+    (void)hipSetDevice(film->device);
+    for (auto& kv : film->last_add) { (void)hipEventSynchronize(kv.second); (void)hipEventDestroy(kv.second); }
+    (void)hipStreamSynchronize(film->stream);
+    film->acc.release(); film->bytes.release(); film->flagged.release();
+    (void)hipStreamDestroy(film->stream);
+    delete film;
+}
+
+const char* sppm_film_last_error(const sppm_film* film) { return film ? film->err.c_str() : "null film"; }
+
+int sppm_film_add(sppm_ctx* ctx, sppm_film* film) {
+    if (!ctx || !film) return SPPM_E_INVALID;
+    if (!ctx->have_eye) return fail(ctx, SPPM_E_INVALID, "sppm_eye_pass must come first");
+    if (ctx->last_rounds == 0) return fail(ctx, SPPM_E_INVALID, "sppm_photon_pass must come first");
+    if (ctx->device != film->device) return fail(ctx, SPPM_E_INVALID, "the film lives on another GPU than the context");
+    if (ctx->cam.w != film->w || ctx->cam.h != film->h) return fail(ctx, SPPM_E_INVALID, "the film has another resolution than the eye pass");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> g(film->mu);
+        auto it = film->last_add.find(ctx);
+        if (it == film->last_add.end()) {
+            HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            film->last_add[ctx] = ev;
+        } else {
+            ev = it->second;
+        }
+    }
+    tic(ctx, PH_RESOLVE);
+    if (ctx->n_hp > 0) {
+        const double inv_norm = 1.0 / SPPM_PI / ((double)ctx->last_rounds * (double)ctx->last_per_round);
+        hipLaunchKernelGGL(k_film_add, dim3((unsigned)((ctx->n_hp + 255) / 256)), dim3(256), 0, ctx->stream, ctx->hp_nr.p, ctx->hp_wgt.p,
+                           ctx->hp_tao.p, (uint32_t)ctx->n_hp, inv_norm, film->acc.p);
+        HIPCHK(hipGetLastError());
+    }
+    toc(ctx);
+    std::lock_guard<std::mutex> g(film->mu);   // a reader on another thread walks last_add
+    HIPCHK(hipEventRecord(ev, ctx->stream));
+    return SPPM_OK;
+}
+
+int sppm_film_clear(sppm_film* film) {
+    if (!film) return SPPM_E_INVALID;
+    std::lock_guard<std::mutex> g(film->mu);
+    FILMCHK(hipSetDevice(film->device));
+    if (int rc = film_join(film)) return rc;
+    FILMCHK(hipMemsetAsync(film->acc.p, 0, film->elems() * sizeof(double), film->stream));
+    FILMCHK(hipStreamSynchronize(film->stream));
+    return SPPM_OK;
+}
+
+int sppm_film_read(sppm_film* film, double* pic_hw3) {
+    if (!film || !pic_hw3) return SPPM_E_INVALID;
+    std::lock_guard<std::mutex> g(film->mu);
+    FILMCHK(hipSetDevice(film->device));
+    if (int rc = film_join(film)) return rc;
+    FILMCHK(hipMemcpyAsync(pic_hw3, film->acc.p, film->elems() * sizeof(double), hipMemcpyDeviceToHost, film->stream));
+    FILMCHK(hipStreamSynchronize(film->stream));
+    return SPPM_OK;
+}
+
+int sppm_film_write(sppm_film* film, const double* pic_hw3) {
+    if (!film || !pic_hw3) return SPPM_E_INVALID;
+    std::lock_guard<std::mutex> g(film->mu);
+    FILMCHK(hipSetDevice(film->device));
+    if (int rc = film_join(film)) return rc;
+    FILMCHK(hipMemcpyAsync(film->acc.p, pic_hw3, film->elems() * sizeof(double), hipMemcpyHostToDevice, film->stream));
+    FILMCHK(hipStreamSynchronize(film->stream));
+    return SPPM_OK;
+}
+
+int sppm_film_tonemap(sppm_film* film, double n_images, int rgb, uint8_t* out_hw3) {
+    if (!film || !out_hw3) return SPPM_E_INVALID;
+    if (!(n_images > 0)) return film_fail(film, SPPM_E_INVALID, "n_images must be positive");
+    std::lock_guard<std::mutex> g(film->mu);
+    FILMCHK(hipSetDevice(film->device));
+    if (int rc = film_join(film)) return rc;
+    const size_t n = film->elems();
+    hipLaunchKernelGGL(k_fill_u32, dim3(1), dim3(64), 0, film->stream, film->flagged.p, (size_t)1, 0u);
+    hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, film->stream, film->acc.p, film->w, film->h, n_images, rgb,
+                       film->bytes.p, film->flagged.p, FILM_FLAG_CAP);
+    FILMCHK(hipGetLastError());
+    uint32_t n_flagged = 0;
+    FILMCHK(hipMemcpyAsync(out_hw3, film->bytes.p, n, hipMemcpyDeviceToHost, film->stream));
+    FILMCHK(hipMemcpyAsync(&n_flagged, film->flagged.p, sizeof(uint32_t), hipMemcpyDeviceToHost, film->stream));
+    FILMCHK(hipStreamSynchronize(film->stream));
+    if (n_flagged == 0) return SPPM_OK;
+    // values on a rounding step of the truncation: decided by the host's exp / pow
+    auto at = [&](size_t e) {
+        const int k = (int)(e % 3);
+        const size_t p = e / 3;
+        const size_t j = p % (size_t)film->w, i1 = p / (size_t)film->w;
+        return ((size_t)(film->h - 1 - (int)i1) * film->w + j) * 3 + (size_t)(rgb ? 2 - k : k);
+    };
+    if (n_flagged <= FILM_FLAG_CAP) {
+        std::vector<uint32_t> idx(n_flagged);
+        FILMCHK(hipMemcpy(idx.data(), film->flagged.p + 1, n_flagged * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint32_t e : idx) {
+            double x = 0;
+            FILMCHK(hipMemcpy(&x, film->acc.p + e, sizeof(double), hipMemcpyDeviceToHost));
+            out_hw3[at(e)] = host_to_int(x / n_images);
+        }
+    } else {
+        std::vector<double> all(n);
+        FILMCHK(hipMemcpy(all.data(), film->acc.p, n * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t e = 0; e < n; e++) out_hw3[at(e)] = host_to_int(all[e] / n_images);
+    }
+    return SPPM_OK;
 }
 
 }  // extern "C"

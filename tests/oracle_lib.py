@@ -37,6 +37,7 @@ SYMBOLS = {
     "oracle_rotated": (None, [_D, _D, C.c_double, _D]),
     "oracle_rand_refl": (None, [_D, C.c_double, C.c_double, _D]),
     "oracle_to_int": (C.c_int, [C.c_double]),
+    "oracle_tonemap": (None, [_D, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]),
     "oracle_hitpoint_update": (None, [_D, C.POINTER(C.c_int32), _D, C.POINTER(C.c_int32)]),
     "oracle_mwc_kat": (None, [C.c_int, C.POINTER(C.c_uint32), _D]),
     "oracle_rng_u32": (C.c_uint32, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -139,3 +140,13 @@ class OracleContext:
                                              dp(out), cap, C.byref(n))
         assert rc == 0, rc
         return out[:n.value]
+
+
+def tonemap(pic_hw3, n_images, rgb=False, lib=None):
+    """The byte image SPPMRayTracer::render writes (raytracer/Raytracer.h:460-466), by the C oracle."""
+    lib = lib or load()
+    pic = np.ascontiguousarray(pic_hw3, dtype=np.float64)
+    h, w, _ = pic.shape
+    out = np.zeros((h, w, 3), dtype=np.uint8)
+    lib.oracle_tonemap(pic.ctypes.data_as(_D), w, h, float(n_images), int(bool(rgb)), out.ctypes.data_as(C.c_void_p))
+    return out

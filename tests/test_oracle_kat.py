@@ -192,6 +192,19 @@ def test_tone_map(lib):
     assert list(scenes.to_int([0.0, 1.0, 1e9])) == [0, 207, 255]
 
 
+def test_written_image_layout(lib):
+    # Raytracer.h:460-466: row h - 1 - i1 of the byte image holds toInt(pic[i1][j][k] / n), channel k at byte k
+    rng = np.random.default_rng(4)
+    pic = rng.gamma(0.5, 0.6, size=(5, 7, 3))
+    got = ol.tonemap(pic, 8.0, lib=lib)
+    for i1 in range(5):
+        for j in range(7):
+            for k in range(3):
+                assert got[4 - i1, j, k] == lib.oracle_to_int(pic[i1, j, k] / 8.0)
+    assert np.array_equal(got, scenes.tonemap_bgr(pic, 8.0))
+    assert np.array_equal(ol.tonemap(pic, 8.0, rgb=True, lib=lib), got[..., ::-1])   # the same picture as a PPM
+
+
 def test_hitpoint_update_is_dead_with_n_zero(lib):
     # Raytracer.h:64-79: N starts at 0 and is only changed behind `if (N <= 0 || newN <= 0) return;`
     R2, N, newN = C.c_double(2.0), C.c_int32(0), C.c_int32(57)
