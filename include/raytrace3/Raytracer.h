@@ -12,10 +12,16 @@
 //   SPPM_DEVICES  comma-separated GPU ids, one library context (= HIP stream) per entry; the four
 //                 replicas of an iteration are dealt over them.  Default "0,0": two contexts on GPU 0,
 //                 so the eye pass of one replica overlaps the photon pass of another.
+//   SPPM_SAVE_EVERY        write the running mean every n-th outer iteration (1, as the reference) and after the last
+//   SPPM_CHECKPOINT        file that receives the fp64 image sum, the iteration count and the jitter generator's state
+//   SPPM_CHECKPOINT_EVERY  ... every n-th outer iteration (10) and after the last
+//   SPPM_RESUME            checkpoint file to continue from
 #pragma once
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
+#include <map>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -39,23 +45,86 @@ inline long long env_ll(const char* name, long long dflt) {
     const char* e = std::getenv(name);
     return (e && *e) ? std::atoll(e) : dflt;
 }
-// Tone-mapped running mean as a binary PPM: rows flipped, and val[0] written as blue, which
-// is what the reference's BGR cv::Mat shows (Raytracer.h:460-470).
-inline bool write_ppm(const std::string& path, const Camera& cam, double n_images) {
+// A byte image [h][w][3] in PPM channel order as a binary PPM.
+inline bool write_ppm(const std::string& path, int w, int h, const std::vector<unsigned char>& rgb) {
     FILE* f = std::fopen(path.c_str(), "wb");
     if (!f) return false;
-    std::fprintf(f, "P6\n%d %d\n255\n", cam.w, cam.h);
-    std::vector<unsigned char> row((size_t)cam.w * 3);
-    for (int i1 = cam.h - 1; i1 >= 0; i1--) {
-        for (int j = 0; j < cam.w; j++)
-            for (int k = 0; k < 3; k++) {
-                int v = toInt(cam.pic[i1][j].val[k] / n_images);
-                row[(size_t)j * 3 + (2 - k)] = (unsigned char)std::min(255, std::max(0, v));
-            }
-        std::fwrite(row.data(), 1, row.size(), f);
+    std::fprintf(f, "P6\n%d %d\n255\n", w, h);
+    const bool ok = std::fwrite(rgb.data(), 1, rgb.size(), f) == rgb.size();
+    return std::fclose(f) == 0 && ok;
+}
+
+// The image sums of the outer SPPM loop, one film per GPU in use (camera.pic of Raytracer.h:449-458 lives on the GPUs).
+struct Films {
+    int w = 0, h = 0;
+    std::map<int, sppm_film*> by_gpu;
+    ~Films() { for (auto& kv : by_gpu) sppm_film_destroy(kv.second); }
+    static void check(int rc, sppm_film* f, const char* what) {
+        if (rc != SPPM_OK) throw std::runtime_error(std::string(what) + " failed: " + sppm_film_last_error(f));
     }
+    sppm_film* on(int gpu) {
+        auto it = by_gpu.find(gpu);
+        if (it != by_gpu.end()) return it->second;
+        sppm_film* f = nullptr;
+        if (sppm_film_create(&f, gpu, w, h) != SPPM_OK) throw std::runtime_error("sppm_film_create failed on GPU " + std::to_string(gpu));
+        by_gpu[gpu] = f;
+        return f;
+    }
+    // fp64 sum over all films, on the host
+    std::vector<double> sum() {
+        std::vector<double> total((size_t)w * h * 3, 0.0), part(total.size());
+        for (auto& kv : by_gpu) {
+            check(sppm_film_read(kv.second, part.data()), kv.second, "sppm_film_read");
+            for (size_t e = 0; e < total.size(); e++) total[e] += part[e];
+        }
+        return total;
+    }
+    // The picture the reference writes (Raytracer.h:460-470: toInt of the running mean, rows flipped), channels in PPM order.
+    std::vector<unsigned char> tonemapped(double n_images) {
+        std::vector<unsigned char> out((size_t)w * h * 3);
+        if (by_gpu.size() == 1) {
+            sppm_film* f = by_gpu.begin()->second;
+            check(sppm_film_tonemap(f, n_images, 1, out.data()), f, "sppm_film_tonemap");
+            return out;
+        }
+        const std::vector<double> total = sum();   // several GPUs: their films meet on the host
+        for (int i1 = 0; i1 < h; i1++)
+            for (int j = 0; j < w; j++)
+                for (int k = 0; k < 3; k++)
+                    out[((size_t)(h - 1 - i1) * w + j) * 3 + (2 - k)] = (unsigned char)toInt(total[((size_t)i1 * w + j) * 3 + k] / n_images);
+        return out;
+    }
+};
+
+// Checkpoint of the outer loop: "SPPMACC1", w, h (i32), iterations done (i64), jitter generator state (u64), w*h*3 doubles.
+inline bool save_checkpoint(const std::string& path, Films& films, long long iterations) {
+    const std::vector<double> total = films.sum();
+    const std::string tmp = path + ".tmp";
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    const int32_t wh[2] = {films.w, films.h};
+    const int64_t it = iterations;
+    const uint64_t st = global_rng().state;
+    bool ok = std::fwrite("SPPMACC1", 1, 8, f) == 8 && std::fwrite(wh, sizeof(wh), 1, f) == 1 && std::fwrite(&it, sizeof(it), 1, f) == 1 &&
+              std::fwrite(&st, sizeof(st), 1, f) == 1 && std::fwrite(total.data(), sizeof(double), total.size(), f) == total.size();
+    ok = std::fclose(f) == 0 && ok;
+    return ok && std::rename(tmp.c_str(), path.c_str()) == 0;   // a reader never sees half a file
+}
+// Returns the number of iterations the checkpoint holds; the sum goes into the film of `gpu`.
+inline long long load_checkpoint(const std::string& path, Films& films, int gpu) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("SPPM_RESUME: cannot open " + path);
+    char magic[8]; int32_t wh[2]; int64_t it = 0; uint64_t st = 0;
+    std::vector<double> total((size_t)films.w * films.h * 3);
+    const bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "SPPMACC1", 8) == 0 && std::fread(wh, sizeof(wh), 1, f) == 1 &&
+                    std::fread(&it, sizeof(it), 1, f) == 1 && std::fread(&st, sizeof(st), 1, f) == 1 && wh[0] == films.w && wh[1] == films.h &&
+                    std::fread(total.data(), sizeof(double), total.size(), f) == total.size();
     std::fclose(f);
-    return true;
+    if (!ok || it < 0) throw std::runtime_error("SPPM_RESUME: " + path + " is not a checkpoint of a " + std::to_string(films.w) + "x" + std::to_string(films.h) + " image");
+    sppm_film* film = films.on(gpu);
+    Films::check(sppm_film_write(film, total.data()), film, "sppm_film_write");
+    global_rng().state = st;
+    return it;
 }
 }  // namespace sppm_host
 
@@ -119,6 +188,16 @@ public:
         eye_locked(dev);
         photon_locked(dev, (int)sppm_host::env_ll("SPPM_ROUNDS", 10000));
     }
+    // render() for the outer loop: the resolved image is added to `film` on the GPU instead of coming back into
+    // camera->pic.  Only queues the photon pass and the add; sppm_synchronize reports what they ran into.
+    void render_into(sppm_film* film) {
+        sppm_host::Device& dev = sppm_host::Device::get(device);
+        std::lock_guard<std::mutex> g(dev.mu);
+        eye_locked(dev);
+        const int cnt = (int)sppm_host::env_ll("SPPM_ROUNDS", 10000), onetime = (int)sppm_host::env_ll("SPPM_ONETIME", 100);
+        dev.check(sppm_photon_pass(dev.ctx, (uint64_t)cnt, (uint32_t)onetime, 0, 0, seed, replica), "sppm_photon_pass");
+        dev.check(sppm_film_add(dev.ctx, film), "sppm_film_add");
+    }
     void debugHitPoint() {
         cout << "HitPoint:size:" << Hvec.size() << endl;
         for (auto e : Hvec) cout << *e;
@@ -175,15 +254,27 @@ private:
 
 class SPPMRayTracer {
 public:
-    // The outer SPPM loop: per iteration four replicas with the camera moved by
-    // 0.00015 * a random unit vector, their images summed, the running mean tone-mapped and
-    // written out (aaanew<i/10>.ppm).  Replicas are spread over SPPM_DEVICES.
+    // The outer SPPM loop (Raytracer.h:421-477): per iteration four replicas with the camera moved by
+    // 0.00015 * a random unit vector, their images summed, the running mean tone-mapped and written out
+    // (aaanew<i/10>.ppm).  Replicas are spread over SPPM_DEVICES; the sum stays on the GPUs.
     void render(Scene scene, Camera camera) {
         const long long sppmtime = sppm_host::env_ll("SPPM_ITERS", 100000);
+        const long long save_every = std::max(1LL, sppm_host::env_ll("SPPM_SAVE_EVERY", 1));
+        const long long ckpt_every = std::max(1LL, sppm_host::env_ll("SPPM_CHECKPOINT_EVERY", 10));
+        const char* ckpt = std::getenv("SPPM_CHECKPOINT");
+        const char* resume = std::getenv("SPPM_RESUME");
         const std::vector<int> devices = sppm_host::env_devices();
+        sppm_host::Films films;
+        films.w = camera.w; films.h = camera.h;
+        long long first = 0;
+        if (resume && *resume) {
+            first = sppm_host::load_checkpoint(resume, films, devices[0]);
+            std::cerr << "resume:" << resume << " at iteration " << first << std::endl;
+        }
         Camera c[4];
-        for (long long i = 0; i < sppmtime; i++) {
+        for (long long i = first; i < sppmtime; i++) {
             RayTracer rt[4];
+            sppm_film* film[4];
             for (int k = 0; k < 4; k++) {
                 c[k] = camera;
                 c[k].MoveTo(camera.pos + 0.00015 * Vec3::GetUnitRandVec());
@@ -192,22 +283,30 @@ public:
                 rt[k].scene = &scene;
                 rt[k].device = (int)((size_t)k % devices.size());   // context slot, see sppm_host::Device::get
                 rt[k].replica = (uint32_t)(i * 4 + k);
+                film[k] = films.on(devices[(size_t)rt[k].device]);
             }
             std::vector<std::thread> th;
             std::vector<std::string> errors(4);
             for (int j = 0; j < 4; j++)
                 th.emplace_back([&, j]() {
-                    try { rt[j].render(); } catch (const std::exception& e) { errors[j] = e.what(); }
+                    try { rt[j].render_into(film[j]); } catch (const std::exception& e) { errors[j] = e.what(); }
                     std::cerr << "Thread " << j << " done" << std::endl;
                 });
             for (auto& t : th) t.join();
             for (const std::string& e : errors) if (!e.empty()) throw std::runtime_error(e);
-            for (int k = 0; k < 4; k++)
-                for (int i1 = 0; i1 < camera.h; i1++)
-                    for (int j = 0; j < camera.w; j++) camera.pic[i1][j] += c[k].pic[i1][j];
-            std::string pic = std::string("aaanew") + std::to_string(i / 10) + std::string(".ppm");
-            std::cerr << "save:" << pic << std::endl;
-            sppm_host::write_ppm(pic, camera, (i + 1) * 4.);
+            for (size_t slot = 0; slot < std::min<size_t>(4, devices.size()); slot++) {   // what the queued passes ran into
+                sppm_host::Device& dev = sppm_host::Device::get((int)slot);
+                std::lock_guard<std::mutex> g(dev.mu);
+                dev.check(sppm_synchronize(dev.ctx), "sppm_synchronize");
+            }
+            const bool last = i + 1 == sppmtime;
+            if ((i + 1) % save_every == 0 || last) {
+                std::string pic = std::string("aaanew") + std::to_string(i / 10) + std::string(".ppm");
+                std::cerr << "save:" << pic << std::endl;
+                if (!sppm_host::write_ppm(pic, camera.w, camera.h, films.tonemapped((i + 1) * 4.))) std::cerr << "cannot write " << pic << std::endl;
+            }
+            if (ckpt && *ckpt && ((i + 1) % ckpt_every == 0 || last))
+                if (!sppm_host::save_checkpoint(ckpt, films, i + 1)) std::cerr << "cannot write " << ckpt << std::endl;
         }
     }
 };

@@ -86,3 +86,50 @@ def test_sppm_loop_over_one_and_two_contexts(tmp_path):
     a, b = pics
     assert a.shape == (48, 64, 3) and a.max() > 50          # something was rendered
     assert np.abs(a.astype(int) - b.astype(int)).max() <= 1  # fp32 summation order only
+
+
+def _run_loop(exe, cwd, **env):
+    e = dict(os.environ, SPPM_SEED="5", SPPM_W="64", SPPM_H="48", SPPM_ROUNDS="40",
+             SPPM_DATA_DIR=os.path.join(ROOT, "raytrace3_amd", "data"))
+    e.update(env)
+    r = subprocess.run([exe], capture_output=True, text=True, env=e, cwd=str(cwd), timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r
+
+
+@pytest.mark.gpu
+def test_sppm_loop_checkpoint_and_resume(tmp_path):
+    """Four outer iterations in one go, and two + a resume from the checkpoint for the other two: the same running
+    mean (the checkpoint holds the fp64 sum, the iteration count and the state of the camera-jitter generator)."""
+    exe = os.path.join(ROOT, "examples", "_build", "sppm_main")
+    whole, part = tmp_path / "whole", tmp_path / "part"
+    whole.mkdir(); part.mkdir()
+    _run_loop(exe, whole, SPPM_ITERS="4", SPPM_CHECKPOINT=str(whole / "sum.acc"), SPPM_SAVE_EVERY="4")
+    _run_loop(exe, part, SPPM_ITERS="2", SPPM_CHECKPOINT=str(part / "sum.acc"))
+    first_half = _read_ppm(part / "aaanew0.ppm").copy()
+    r = _run_loop(exe, part, SPPM_ITERS="4", SPPM_RESUME=str(part / "sum.acc"), SPPM_CHECKPOINT=str(part / "sum2.acc"))
+    assert "at iteration 2" in r.stderr
+    a, b = _read_ppm(whole / "aaanew0.ppm"), _read_ppm(part / "aaanew0.ppm")
+    assert a.max() > 50 and not np.array_equal(first_half, b)
+    # fp64 sums whose additions may come in another order: the same bytes up to a rounding step of toInt
+    assert np.abs(a.astype(int) - b.astype(int)).max() <= 1 and (a != b).mean() < 1e-3
+
+    def load(p):
+        raw = open(p, "rb").read()
+        assert raw[:8] == b"SPPMACC1"
+        w, h = np.frombuffer(raw, dtype=np.int32, count=2, offset=8)
+        iters = int(np.frombuffer(raw, dtype=np.int64, count=1, offset=16)[0])
+        return iters, np.frombuffer(raw, dtype=np.float64, offset=32).reshape(h, w, 3)
+    it_a, sum_a = load(whole / "sum.acc")
+    it_b, sum_b = load(part / "sum2.acc")
+    assert it_a == it_b == 4
+    # the same deposits in both runs; the order in which a HitPoint's fp32 flux sums them varies from run to run
+    assert np.allclose(sum_a, sum_b, rtol=1e-4, atol=1e-6 * sum_a.mean())
+    # the written picture is toInt of that sum over 4 x 4 images (Raytracer.h:460-470), in PPM channel order
+    from tests import oracle_lib as ol
+    assert np.array_equal(a, ol.tonemap(sum_a, 16.0, rgb=True))
+    # a checkpoint of another resolution is refused
+    bad = subprocess.run([exe], capture_output=True, text=True, cwd=str(part), timeout=300,
+                         env=dict(os.environ, SPPM_W="32", SPPM_H="48", SPPM_ITERS="1", SPPM_RESUME=str(part / "sum.acc"),
+                                  SPPM_DATA_DIR=os.path.join(ROOT, "raytrace3_amd", "data")))
+    assert bad.returncode != 0
