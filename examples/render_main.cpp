@@ -3,7 +3,9 @@
 // of the reference scene.  Writes the resolved flux image as raw doubles ([h][w][3]) so the
 // tests can compare it with the Python-driven path and the oracle.
 //
-//   render_main <out.f64> [w h rounds replica]
+//   render_main <out.f64> [w h rounds replica [stock]]
+// With a sixth argument the scene is the reference's own Scene::init() (textures: <name>.ppm next to the working
+// directory or in SPPM_DATA_DIR, procedural stand-ins otherwise).
 #include <cstdio>
 #include <cstdlib>
 
@@ -16,7 +18,7 @@
 #include "Vec3.h"
 
 int main(int argc, char** argv) {
-    if (argc < 2) { std::fprintf(stderr, "usage: %s out.f64 [w h rounds replica]\n", argv[0]); return 2; }
+    if (argc < 2) { std::fprintf(stderr, "usage: %s out.f64 [w h rounds replica [stock]]\n", argv[0]); return 2; }
     const int w = argc > 2 ? std::atoi(argv[2]) : 64, h = argc > 3 ? std::atoi(argv[3]) : 64;
     const int rounds = argc > 4 ? std::atoi(argv[4]) : 100;
     const unsigned replica = argc > 5 ? (unsigned)std::atoi(argv[5]) : 0;
@@ -28,6 +30,9 @@ int main(int argc, char** argv) {
     camera.lookAt(org + Vec3(0, 0.042612, -1), 1 / 1.);
 
     Scene scene;
+    if (argc > 6) {
+        scene.init();
+    } else {
     const Material WHITE_DIFF(Vec3(.75, .75, .75), Vec3(), Vec3(), 0);
     const Material MIRROR(Vec3(), Vec3(1, 1, 1) * .999, Vec3(), 0);
     const Material REFR0(Vec3(), Vec3(), Vec3(.999, .999, .999), 1.5);
@@ -46,6 +51,7 @@ int main(int argc, char** argv) {
     Trans2(2, 0) = -std::sin(theta); Trans2(2, 2) = std::cos(theta);
     scene.objvec.push_back(new Bezier3Obj(Vec3(20, 0, 120), 4, "teapot.bpt", Vec3(0, .999, .999), WHITE_DIFF, Trans2 * Trans));
     scene.plvec.push_back(new SpotLight(Vec3(50, 60, 85), 5000 * Color(1, 1, 1)));
+    }
 
     RayTracer r1;
     r1.camera = &camera;

@@ -53,18 +53,6 @@ public:
     }
 };
 
-namespace sppm_host {
-// Directory searched for .bpt files that are not found relative to the working directory.
-inline std::string data_dir() {
-    if (const char* e = std::getenv("SPPM_DATA_DIR")) return e;
-#ifdef SPPM_DEFAULT_DATA_DIR
-    return SPPM_DEFAULT_DATA_DIR;
-#else
-    return ".";
-#endif
-}
-}  // namespace sppm_host
-
 class Bezier3Obj : public Obj {
     std::vector<Bezier3> Bvec;
     AABBbox aabb;

@@ -1,19 +1,32 @@
 // Element.h — drop-in for the reference's raytracer/Element.h (Ray, Material, Collision,
 // Texture; raytracer/Element.h:6-75) without OpenCV.  Texture reads binary PPM (P6) files;
 // for any other file name (the reference's .jpg names) it looks for a .ppm of the same
-// base name and otherwise builds a seeded procedural image, because JPEG decoding is not
+// base name, in the working directory and then in SPPM_DATA_DIR, and otherwise builds a seeded procedural image, because JPEG decoding is not
 // part of the accelerated path.  Texel storage is rows x cols x 3 bytes in the reference's
 // channel order (OpenCV BGR), value = byte / 255.
 #pragma once
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <string>
 #include <vector>
 
 #include "Vec3.h"
+
+namespace sppm_host {
+// Directory searched for .bpt and texture files that are not found relative to the working directory.
+inline std::string data_dir() {
+    if (const char* e = std::getenv("SPPM_DATA_DIR")) return e;
+#ifdef SPPM_DEFAULT_DATA_DIR
+    return SPPM_DEFAULT_DATA_DIR;
+#else
+    return ".";
+#endif
+}
+}  // namespace sppm_host
 
 class Obj;
 struct Ray {
@@ -58,7 +71,7 @@ struct Texture {
             size_t dot = alt.find_last_of('.');
             if (dot != std::string::npos) alt = alt.substr(0, dot);
             alt += ".ppm";
-            if (!load_ppm(alt)) {
+            if (!load_ppm(alt) && !load_ppm(sppm_host::data_dir() + "/" + alt)) {
                 procedural(fileName);
                 std::cerr << "Texture: " << fileName << " not readable as PPM, using a procedural stand-in" << std::endl;
             }

@@ -87,6 +87,38 @@ def procedural_texture(name, rows=256, cols=256, seed=20260101):
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
+def load_ppm(path):
+    """A binary PPM (P6, maxval 255) as the reference's texture map: rows x cols x 3 bytes in the BGR order of
+    cv::imread (raytracer/Element.h:47-59)."""
+    with open(path, "rb") as f:
+        raw = f.read()
+    tokens, pos = [], 0
+    while len(tokens) < 4:                      # magic, width, height, maxval; '#' starts a comment
+        while raw[pos:pos + 1].isspace():
+            pos += 1
+        if raw[pos:pos + 1] == b"#":
+            pos = raw.index(b"\n", pos) + 1
+            continue
+        end = pos
+        while not raw[end:end + 1].isspace():
+            end += 1
+        tokens.append(raw[pos:end])
+        pos = end
+    if tokens[0] != b"P6" or int(tokens[3]) != 255:
+        raise ValueError(f"{path}: not a binary PPM with maxval 255")
+    w, h = int(tokens[1]), int(tokens[2])
+    rgb = np.frombuffer(raw, dtype=np.uint8, count=w * h * 3, offset=pos + 1).reshape(h, w, 3)
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+def save_ppm(path, bgr):
+    """Writes a rows x cols x 3 BGR byte image as a binary PPM."""
+    bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (bgr.shape[1], bgr.shape[0]))
+        f.write(np.ascontiguousarray(bgr[:, :, ::-1]).tobytes())
+
+
 class FlatScene:
     """Builder + owner of the arrays behind one sppm_scene."""
 
@@ -237,15 +269,17 @@ def scene_spheres_plane(box=False):
     return s
 
 
-def scene_teapot(n_teapots=1, textured=True):
+def scene_teapot(n_teapots=1, textured=True, textures=None):
     """Config 2 (n_teapots=1): the full scene of Scene.h:116-157 — 5 planes, 3 spheres,
     teapot.bpt scaled 4 at (20,0,120), textures on walls / floor / small sphere / teapot.
-    Config 4 (n_teapots=4): three more teapots inside the tunnel (128 patches)."""
+    Config 4 (n_teapots=4): three more teapots inside the tunnel (128 patches).
+    textures: optional {"timg" | "wall" | "planet" | "blue": rows x cols x 3 BGR bytes} in place of the
+    procedural stand-ins (what Texture("timg.jpg") etc. of Scene.h:131-156 load)."""
     s = FlatScene()
     tex = {}
     if textured:
         for name in ("timg", "wall", "planet", "blue"):
-            tex[name] = s.add_texture(procedural_texture(name))
+            tex[name] = s.add_texture(textures[name] if textures and name in textures else procedural_texture(name))
     t = lambda k: tex.get(k, -1)
     s.add_plane((1, 40.8, 81.6), (1, 0, 0), (.75, .25, .25), WHITE_DIFF, t("wall"))     # Left
     s.add_plane((99, 40.8, 81.6), (1, 0, 0), (.25, .25, .75), WHITE_DIFF, t("wall"))    # Right

@@ -133,3 +133,56 @@ def test_sppm_loop_checkpoint_and_resume(tmp_path):
                          env=dict(os.environ, SPPM_W="32", SPPM_H="48", SPPM_ITERS="1", SPPM_RESUME=str(part / "sum.acc"),
                                   SPPM_DATA_DIR=os.path.join(ROOT, "raytrace3_amd", "data")))
     assert bad.returncode != 0
+
+
+@pytest.mark.gpu
+def test_stock_scene_with_ppm_textures(tmp_path):
+    """Scene::init() (raytracer/Scene.h:98-164) with its four textures read from binary PPM files: the C++ host,
+    the ctypes host given the same texel arrays, and the oracle agree (Texture::colorUV, Element.h:61-72, runs on
+    the device)."""
+    import shutil
+    from raytrace3_amd import SppmContext, scenes
+    from tests import oracle_lib as ol
+    rng = np.random.default_rng(8)
+    tex = {}
+    for name, (rows, cols) in {"timg": (37, 53), "wall": (64, 48), "planet": (20, 31), "blue": (16, 16)}.items():
+        tex[name] = rng.integers(0, 256, size=(rows, cols, 3), dtype=np.uint8)
+        scenes.save_ppm(tmp_path / (name + ".ppm"), tex[name])
+        assert np.array_equal(scenes.load_ppm(tmp_path / (name + ".ppm")), tex[name])
+    shutil.copy(os.path.join(ROOT, "raytrace3_amd", "data", "teapot.bpt"), tmp_path / "teapot.bpt")
+    exe = os.path.join(ROOT, "examples", "_build", "render_main")
+    out = tmp_path / "pic.f64"
+    env = dict(os.environ, SPPM_SEED="78", SPPM_DATA_DIR=str(tmp_path))     # textures and teapot.bpt found through the data dir
+    r = subprocess.run([exe, str(out), "48", "40", "60", "1", "stock"], capture_output=True, text=True, env=env, timeout=120,
+                       cwd=str(tmp_path.parent))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "procedural" not in r.stderr
+    cpp = np.fromfile(out, dtype=np.float64).reshape(40, 48, 3)
+    scene = scenes.scene_teapot(1, textures=tex)
+    cam = scenes.default_camera(48, 40)
+    g = SppmContext(0)
+    g.set_scene(scene)
+    g.eye_pass(cam, 78, replica=1)
+    g.photon_pass(60, 100, 78, replica=1)
+    py = g.resolve()
+    g.close()
+    assert cpp.mean() > 0
+    assert np.allclose(cpp, py, rtol=1e-4, atol=1e-6 * py.mean())
+    o = ol.OracleContext()
+    o.set_scene(scene)
+    o.eye_pass(cam, 78, replica=1)
+    o.photon_pass(60, 100, 78, replica=1)
+    c = o.resolve()
+    diff = np.abs(cpp - c).max(axis=2) / c.mean()
+    assert (diff <= 1e-3).mean() >= 0.97 and diff.mean() <= 2e-3
+    # the textures matter: the same scene with the stand-ins gives another picture
+    assert not np.allclose(c, _oracle_image(scenes.scene_teapot(1), cam, 78, 1), rtol=1e-2, atol=1e-3 * c.mean())
+
+
+def _oracle_image(scene, cam, seed, replica):
+    from tests import oracle_lib as ol
+    o = ol.OracleContext()
+    o.set_scene(scene)
+    o.eye_pass(cam, seed, replica=replica)
+    o.photon_pass(60, 100, seed, replica=replica)
+    return o.resolve()
