@@ -217,6 +217,8 @@ struct TraceParams {
     const DevLight* lights; int n_lights; uint32_t per_round;
     Deposit* dep; unsigned long long* n_dep; unsigned long long dep_cap;
     uint32_t* dcount; GridParams grid;
+    const uint8_t* occ;                       // one byte per bucket: some HitPoint lies within one cell of a cell of that bucket
+                                              // (null: every deposit is kept)
     unsigned long long* wave_chunks;          // per wave slot {next, end} of its open deposit-slot chunk
 };
 
@@ -480,7 +482,7 @@ __global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneP
                 else atomicOr(&tp.counters->overflow, 2u);
             }
         } else {
-            bool dp = false;
+            bool dp = false, keep = false;
             PosKey da;
             DepB db;
             if (active) {
@@ -493,7 +495,10 @@ __global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneP
                     da.key = cell_key(hit.pos, tp.grid.inv_cs);
                     db.nx = (float)hit.n.x; db.ny = (float)hit.n.y; db.nz = (float)hit.n.z;
                     db.fr = carry[0]; db.fg = carry[1]; db.fb = carry[2];
-                    db.bucket = key_bucket(da.key, tp.grid.mask) | (vertex << 24); db.photon = id;
+                    const uint32_t bk = key_bucket(da.key, tp.grid.mask);
+                    db.bucket = bk | (vertex << 24); db.photon = id;
+                    // no HitPoint in the 27 cells around: the gather would never look at this deposit
+                    keep = !tp.occ || tp.occ[bk] != 0;
                 }
                 // Obj::Roulette, Obj.h:30-45
                 const double r = rng_u01(rng_sub(tp.rng, id, vertex, P_ROULETTE), 0) * ob.allr;
@@ -515,9 +520,10 @@ __global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneP
                 o = hit.pos; d = nd;
                 if (dep > SPPM_MAX_DEP) active = false;                                   // Raytracer.h:126-133
             }
+            if (dp) ndep++;
+            dp = dp && keep;
             const unsigned long long slot = chunk_alloc(dp, slot_next, slot_end, tp.n_dep, TRACE_SLOT_CHUNK);
             if (dp) {
-                ndep++;
                 if (slot < tp.dep_cap) {
                     Deposit rec; rec.a = da; rec.b = db;
                     tp.dep[slot] = rec;
@@ -679,6 +685,23 @@ __global__ void k_hp_scatter(const RawHit* hits, uint32_t n, GridParams g, const
     hp_tao[s] = make_float4(0, 0, 0, __int_as_float(0));                                  // tao = 0, newN = 0
     HpMeta m; m.v[0] = h.v[0]; m.v[1] = h.v[1]; m.v[2] = h.v[2]; m.node = h.node; m.obj = h.obj; m.N = 0;
     hp_meta[s] = m;
+}
+
+// Which buckets can hold a deposit that some HitPoint gathers: the cells of the HitPoints, widened by one cell
+// in every direction (the gather of a cell looks at exactly those 27).  One thread per HitPoint of the sorted
+// array; only the first of a run of equal cells does the marking.  A byte per bucket, set by plain stores:
+// neighbouring cells mark the same few buckets over and over, which read-modify-write atomics would serialise.
+__global__ void k_hp_occupancy(const PosKey* __restrict__ hp_pos, uint32_t n, GridParams g, uint8_t* occ) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = hp_pos[i].key;
+    if (i > 0 && hp_pos[i - 1].key == key) return;
+#pragma unroll
+    for (int c = 0; c < 27; c++) {
+        const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
+        const uint64_t nb_key = key + ((uint64_t)(int64_t)dx << 42) + ((uint64_t)(int64_t)dy << 21) + (uint64_t)(int64_t)dz;
+        occ[key_bucket(nb_key, g.mask)] = 1;
+    }
 }
 
 __global__ void k_dep_scatter(const Deposit* __restrict__ dep, const unsigned long long* n_dep, unsigned long long cap,
@@ -1113,10 +1136,14 @@ struct sppm_ctx {
     int scatter_blocks_per_cu = 32;
     bool verbose = false;
     DevBuf<uint32_t> bucket_of, hstart;
-    DevBuf<uint32_t> hist;                // HitPoint histogram | scatter cursors | deposit histogram, (M + 1) words each
-    uint32_t* hcount() const { return hist.p; }
-    uint32_t* cursor() const { return hist.p + ((size_t)grid.mask + 2); }
-    uint32_t* dcount() const { return hist.p + 2 * ((size_t)grid.mask + 2); }
+    // bucket occupancy bytes (M / 4 words) | HitPoint histogram | scatter cursors | deposit histogram ((M + 1) words each)
+    DevBuf<uint32_t> hist;
+    size_t occ_words() const { return ((size_t)grid.mask + 1) / 4; }
+    uint8_t* occ() const { return (uint8_t*)hist.p; }
+    uint32_t* hcount() const { return hist.p + occ_words(); }
+    uint32_t* cursor() const { return hcount() + ((size_t)grid.mask + 2); }
+    uint32_t* dcount() const { return hcount() + 2 * ((size_t)grid.mask + 2); }
+    bool dep_filter = true;               // deposits no HitPoint can reach are not stored (SPPM_DEP_FILTER=0 keeps them)
     bool has_dual_lobe = false;           // some material reflects and refracts: eye paths branch
     DevBuf<PosKey> hp_pos; DevBuf<float4> hp_nr, hp_wgt, hp_tao; DevBuf<HpMeta> hp_meta;
     uint64_t n_hp = 0;
@@ -1164,6 +1191,7 @@ struct sppm_ctx {
         }                                                                                    \
     } while (0)
 
+static uint32_t* hist_words(sppm_ctx* ctx) { return ctx->hist.p; }
 static int fail(sppm_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
     return code;
@@ -1231,6 +1259,7 @@ int sppm_create(sppm_ctx** out, int device_id) {
     if (const char* b = getenv("SPPM_TRACE_BPC")) ctx->trace_blocks_per_cu = std::max(0, atoi(b));
     if (const char* b = getenv("SPPM_EYE_BPC")) ctx->eye_blocks_per_cu = std::max(0, atoi(b));
     if (const char* b = getenv("SPPM_NEWTON_BPC")) ctx->newton_blocks_per_cu = std::max(1, atoi(b));
+    if (const char* b = getenv("SPPM_DEP_FILTER")) ctx->dep_filter = atoi(b) != 0;
     if (const char* b = getenv("SPPM_VERBOSE")) ctx->verbose = atoi(b) != 0;
     if (ctx->ctl.reserve(ctx->ctl_words()) != hipSuccess || ctx->counters.reserve(1) != hipSuccess) {
         (void)hipStreamDestroy(ctx->stream);
@@ -1618,18 +1647,19 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
     if (int rc = close_chunks(ctx, nullptr, ctx->raw.p, hit_cap)) return rc;
     HIPCHK(ctx->bucket_of.reserve(std::max<uint64_t>(claimed, 1)));
     // hcount | cursor | dcount are one allocation: a pass clears two neighbours with one fill
-    HIPCHK(ctx->hist.reserve(3 * ((size_t)M + 1)));
+    HIPCHK(ctx->hist.reserve(ctx->occ_words() + 3 * ((size_t)M + 1)));
     HIPCHK(ctx->hstart.reserve(M + 1)); HIPCHK(ctx->dstart.reserve(M + 1));
     HIPCHK(ctx->hp_pos.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_nr.reserve(std::max<uint64_t>(n, 1)));
     HIPCHK(ctx->hp_wgt.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_tao.reserve(std::max<uint64_t>(n, 1)));
     HIPCHK(ctx->hp_meta.reserve(std::max<uint64_t>(n, 1)));
-    if (int rc = launch_fill(ctx, ctx->hcount(), 2 * ((size_t)M + 1), 0)) return rc;
+    if (int rc = launch_fill(ctx, hist_words(ctx), ctx->occ_words() + 2 * ((size_t)M + 1), 0)) return rc;   // occupancy, hcount, cursor
     if (n > 0) {
         const int blocks = (int)((claimed + 255) / 256);
         hipLaunchKernelGGL(k_hp_count, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)claimed, ctx->grid, ctx->bucket_of.p, ctx->hcount());
         if (int rc = launch_scan(ctx, ctx->hcount(), ctx->hstart.p, M)) return rc;
         hipLaunchKernelGGL(k_hp_scatter, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)claimed, ctx->grid, ctx->bucket_of.p,
                            ctx->hstart.p, ctx->cursor(), ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->hp_tao.p, ctx->hp_meta.p);
+        hipLaunchKernelGGL(k_hp_occupancy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->hp_pos.p, (uint32_t)n, ctx->grid, ctx->occ());
         HIPCHK(hipGetLastError());
     }
     toc(ctx);
@@ -1643,6 +1673,7 @@ static void fill_photon_params(sppm_ctx* ctx, TraceParams& tp, uint32_t per_roun
     tp.lights = ctx->lights.p; tp.n_lights = ctx->n_lights; tp.per_round = per_round;
     tp.dep = ctx->dep.p; tp.n_dep = ctx->scalars() + SC_DEP; tp.dep_cap = dep_cap;
     tp.dcount = ctx->dcount(); tp.grid = ctx->grid; tp.counters = counters;
+    tp.occ = ctx->dep_filter ? ctx->occ() : nullptr;
     tp.wave_chunks = ctx->wave_chunks();
     tp.rng = host_rng_base(seed, replica * 4u + D_PHOTON);
 }
@@ -1870,6 +1901,7 @@ int sppm_debug_photon_deposits(sppm_ctx* ctx, uint64_t rounds, uint32_t per_roun
     HIPCHK(hipMemsetAsync(scratch_counters.p, 0, sizeof(DevCounters), ctx->stream));
     TraceParams tp{};
     fill_photon_params(ctx, tp, per_round, dep_cap, seed, replica, scratch_counters.p);
+    tp.occ = nullptr;                       // the parity hook returns every deposit, reachable by a HitPoint or not
     const uint32_t M = ctx->grid.mask + 1;
     int rrc = reset_ctl(ctx);
     if (rrc == SPPM_OK) rrc = launch_fill(ctx, ctx->dcount(), (size_t)M + 1, 0);
