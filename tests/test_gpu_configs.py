@@ -210,6 +210,30 @@ def test_batch_size_is_immaterial(gpu):
     small.close()
 
 
+def test_dropping_unreachable_deposits_changes_nothing(gpu):
+    """Deposits with no HitPoint in the 27 cells around them are not stored (most of them in the open tunnel of
+    the teapot scene).  A context that keeps them all (SPPM_DEP_FILTER=0) sees the same pairs: equal counters and
+    per-HitPoint photon counts, the fluxes up to the order of their fp32 sums."""
+    scene, cam = scenes.scene_teapot(1), scenes.default_camera(160, 120)
+    gpu.set_scene(scene)
+    gpu.eye_pass(cam, SEED)
+    gpu.photon_pass(500, 100, SEED)
+    os.environ["SPPM_DEP_FILTER"] = "0"
+    try:
+        keep = SppmContext(0)
+    finally:
+        del os.environ["SPPM_DEP_FILTER"]
+    keep.set_scene(scene)
+    keep.eye_pass(cam, SEED)
+    keep.photon_pass(500, 100, SEED)
+    assert keep.counters() == gpu.counters() and gpu.counters()["accepted"] > 0
+    a, b = gpu.hitpoints(), keep.hitpoints()
+    a, b = a[np.argsort(_key(a))], b[np.argsort(_key(b))]
+    assert np.array_equal(_key(a), _key(b)) and np.array_equal(a["newN"], b["newN"])
+    assert np.allclose(a["tao"], b["tao"], rtol=1e-4, atol=1e-6 * a["tao"].mean())
+    keep.close()
+
+
 # ------------------------------------------------------------------ materials, lights, depth
 def _materials_scene():
     """Floor + back mirror + three spheres: glass that also reflects (eye paths branch, Raytracer.h:320-336),

@@ -30,8 +30,9 @@ def cpu(config, threads, rounds):
     return {"threads": threads, "photons": ph, "eye_s": te, "photon_s": tp, "mphotons_per_s": ph / tp / 1e6,
             "ms_per_iter_extrapolated": None}
 
-out = {"cpu": {}, "gpu": {}}
-for config, rounds in (("c1_spheres_plane_256", 1000), ("c2_teapot_800x600", 500), ("c4_teapot4_1080p", 100), ("c5_caustic_1024", 2000)):
+GPU_ONLY = "--gpu-only" in sys.argv     # the CPU rows do not change with the kernels
+out = {"cpu": {}, "gpu": {}, "gpu_single_stream": {}}
+for config, rounds in (() if GPU_ONLY else (("c1_spheres_plane_256", 1000), ("c2_teapot_800x600", 500), ("c4_teapot4_1080p", 100), ("c5_caustic_1024", 2000))):
     full_rounds = scenes.CONFIGS[config][2]
     for threads in (4, 16):
         r = cpu(config, threads, rounds)
@@ -41,10 +42,11 @@ for config, rounds in (("c1_spheres_plane_256", 1000), ("c2_teapot_800x600", 500
         out["cpu"][f"{config}/{threads}"] = r
         print(config, threads, r, flush=True)
 for config in ("c1_spheres_plane_256", "c2_teapot_800x600", "c4_teapot4_1080p", "c5_caustic_1024"):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "5", "--no-cpu-baseline"],
-                       capture_output=True, text=True, timeout=600)
-    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    out["gpu"][config] = json.loads(line[-1]) if line else {"error": p.stderr[-500:]}
-    print(config, out["gpu"][config].get("value"), flush=True)
+    for key, extra in (("gpu", []), ("gpu_single_stream", ["--inflight", "1"])):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "10", "--no-cpu-baseline"] + extra,
+                           capture_output=True, text=True, timeout=600)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        out[key][config] = json.loads(line[-1]) if line else {"error": p.stderr[-500:]}
+        print(config, key, out[key][config].get("value"), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "table.json"), "w"), indent=1)
