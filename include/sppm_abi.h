@@ -224,6 +224,16 @@ int sppm_synchronize(sppm_ctx* ctx);
  * of waiting for the stream after each); accumulate = 0 clears them and restores the default. */
 int sppm_stats_mode(sppm_ctx* ctx, int accumulate);
 
+/* A context queues its work on a HIP stream of its own.  sppm_set_stream makes it use the caller's stream
+ * (a hipStream_t of the context's GPU; NULL: back to its own) from the next call on, after waiting for what it
+ * had queued so far, so that a host can order the library's passes with its own GPU work (a collective on the
+ * image sppm_resolve_device wrote) by stream order instead of waiting on the host.  The stream stays the
+ * caller's: it must outlive the context or be replaced first.  No counterpart in the reference. */
+int sppm_set_stream(sppm_ctx* ctx, void* hip_stream);
+/* The hipStream_t the context queues on at present (its own unless sppm_set_stream replaced it), for a host
+ * that wants to put its own work behind the library's on the same stream.  No counterpart in the reference. */
+void* sppm_get_stream(const sppm_ctx* ctx);
+
 /* Copy out up to cap HitPoints; *n receives |Hvec|. */
 int sppm_get_hitpoints(sppm_ctx* ctx, sppm_hitpoint* out, uint64_t cap, uint64_t* n);
 int sppm_get_counters(sppm_ctx* ctx, sppm_counters* out);

@@ -6,6 +6,7 @@ CPU fallback in the product path.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -103,6 +104,8 @@ ABI_SYMBOLS = {
     "sppm_film_tonemap": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_void_p]),
     "sppm_film_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "sppm_film_write": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "sppm_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sppm_get_stream": (C.c_void_p, [C.c_void_p]),
     "sppm_synchronize": (C.c_int, [C.c_void_p]),
     "sppm_stats_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "sppm_get_hitpoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
@@ -128,6 +131,14 @@ def bind(lib, symbols):
 def load_library(path=None):
     # SPPM_LIB_PATH selects another build of the same library (kernel A/B experiments)
     path = path or os.environ.get("SPPM_LIB_PATH") or LIB_PATH
+    # PyTorch wheels carry their own copy of the ROCm runtime.  Two copies in one process do not both get the GPU:
+    # the one loaded second reports "no HIP GPUs".  Loaded after torch, this library binds to torch's copy and
+    # all is well, so a process that has torch (bench.py and the multi-GPU host do use it, for streams and RCCL)
+    # lets torch load first.  SPPM_NO_TORCH_PRELOAD=1 skips this for a host that never touches torch.
+    if "torch" not in sys.modules and not os.environ.get("SPPM_NO_TORCH_PRELOAD"):
+        import importlib.util
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -195,6 +206,15 @@ class SppmContext:
     def synchronize(self):
         """Wait for the queued passes; raises if one of them overflowed a queue."""
         self._check(self.lib.sppm_synchronize(self._ctx), "sppm_synchronize")
+
+    def set_stream(self, hip_stream):
+        """Queue this context's passes on the caller's HIP stream (an integer handle such as
+        torch.cuda.Stream().cuda_stream; None / 0: back to the context's own stream)."""
+        self._check(self.lib.sppm_set_stream(self._ctx, C.c_void_p(int(hip_stream or 0))), "sppm_set_stream")
+
+    def stream_handle(self):
+        """The HIP stream this context queues on, as an integer (torch.cuda.ExternalStream(handle) wraps it)."""
+        return int(self.lib.sppm_get_stream(self._ctx) or 0)
 
     def stats_mode(self, accumulate):
         """accumulate=True: counters / timings run on over passes from now; False: restart at each eye pass."""

@@ -1112,7 +1112,8 @@ uint32_t next_pow2(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p
 #define CTL_SCALARS 16
 struct sppm_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;         // the stream every pass is queued on: own_stream, or the caller's (sppm_set_stream)
+    hipStream_t own_stream = nullptr;
     std::string err;
     // scene
     bool have_scene = false;
@@ -1242,10 +1243,11 @@ int sppm_create(sppm_ctx** out, int device_id) {
     ctx->device = device_id;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
-    if (hipStreamCreate(&ctx->stream) != hipSuccess) {
+    if (hipStreamCreate(&ctx->own_stream) != hipSuccess) {
         delete ctx;
         return SPPM_E_DEVICE;
     }
+    ctx->stream = ctx->own_stream;
     if (const char* b = getenv("SPPM_BATCH")) {
         long long v = atoll(b);
         if (v > 0) ctx->batch = (uint64_t)v;
@@ -1262,7 +1264,7 @@ int sppm_create(sppm_ctx** out, int device_id) {
     if (const char* b = getenv("SPPM_DEP_FILTER")) ctx->dep_filter = atoi(b) != 0;
     if (const char* b = getenv("SPPM_VERBOSE")) ctx->verbose = atoi(b) != 0;
     if (ctx->ctl.reserve(ctx->ctl_words()) != hipSuccess || ctx->counters.reserve(1) != hipSuccess) {
-        (void)hipStreamDestroy(ctx->stream);
+        (void)hipStreamDestroy(ctx->own_stream);
         delete ctx;
         return SPPM_E_DEVICE;
     }
@@ -1284,7 +1286,7 @@ void sppm_destroy(sppm_ctx* ctx) {
     ctx->dep.release(); ctx->sdep.release(); ctx->pieces.release();
     ctx->dstart.release(); ctx->scan_partial.release(); ctx->ctl.release(); ctx->counters.release(); ctx->pic.release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
@@ -1697,6 +1699,16 @@ int sppm_stats_mode(sppm_ctx* ctx, int accumulate) {
     HIPCHK(hipMemsetAsync(ctx->counters.p, 0, offsetof(DevCounters, overflow), ctx->stream));
     return SPPM_OK;
 }
+
+int sppm_set_stream(sppm_ctx* ctx, void* hip_stream) {
+    if (!ctx) return SPPM_E_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));     // nothing of this context is left behind on the old stream
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SPPM_OK;
+}
+
+void* sppm_get_stream(const sppm_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 int sppm_synchronize(sppm_ctx* ctx) {
     if (!ctx) return SPPM_E_INVALID;

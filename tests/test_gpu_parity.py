@@ -281,3 +281,44 @@ def test_empty_and_error_paths(gpu):
     assert fresh.resolve().sum() == 0
     assert fresh.counters()["photons"] == 200
     fresh.close()
+
+
+def test_context_on_the_callers_stream():
+    """sppm_set_stream: the passes queue on a stream the host owns, so work the host puts on that stream after
+    sppm_resolve_device (here a torch reduction, in bench.py the all-reduce) sees the finished image with no
+    host-side wait in between; back on its own stream the context gives the same image."""
+    import torch
+    scene, cam = scenes.scene_teapot(1), scenes.default_camera(96, 72)
+    g = SppmContext(0)
+    try:
+        g.set_scene(scene)
+        g.eye_pass(cam, SEED, 2)
+        g.photon_pass(200, 100, SEED, 2)
+        want = g.resolve()
+        pic = torch.zeros((72, 96, 3), dtype=torch.float32, device="cuda")   # torch sets itself up before it hands out streams
+        st = torch.cuda.Stream()
+        g.set_stream(st.cuda_stream)
+        for _ in range(3):                      # queued back to back: the image buffer is reused in stream order
+            g.eye_pass(cam, SEED, 2)
+            g.photon_pass(200, 100, SEED, 2)
+            g.resolve_device(pic.data_ptr())
+            with torch.cuda.stream(st):
+                doubled = pic * 2               # ordered after the resolve by the stream alone
+        st.synchronize()
+        g.synchronize()
+        assert np.allclose(doubled.cpu().numpy(), 2 * want, rtol=2e-4, atol=1e-6 * want.mean())
+        assert g.stream_handle() == st.cuda_stream
+        g.set_stream(None)
+        # back on its own stream, seen by torch as an external stream (what bench.py does)
+        own = torch.cuda.ExternalStream(g.stream_handle())
+        assert g.stream_handle() != st.cuda_stream
+        g.eye_pass(cam, SEED, 2)
+        g.photon_pass(200, 100, SEED, 2)
+        g.resolve_device(pic.data_ptr())
+        with torch.cuda.stream(own):
+            tripled = pic * 3
+        own.synchronize()
+        assert np.allclose(tripled.cpu().numpy(), 3 * want, rtol=2e-4, atol=1e-6 * want.mean())
+        assert np.allclose(g.resolve(), want, rtol=2e-4, atol=1e-6 * want.mean())
+    finally:
+        g.close()
