@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: sweep.sh  -- runs bench.py under several grid-size settings with 2..4 iterations in flight
+# Runs bench.py under several persistent-grid sizes (SPPM_TRACE_BPC / SPPM_GATHER_BPC) with 2..4 iterations in flight.
 cd "${GRAFT_REPO_ROOT:-.}"
 run() {
   local label="$1"; shift

@@ -1,3 +1,5 @@
+"""Diagnostic (GPU box): the fraction of a pass's deposits that have a HitPoint within one grid cell, i.e. that any
+gather can reach, per configuration.  python tools/deposit_reach.py"""
 import numpy as np, sys
 sys.path.insert(0, '.')
 from raytrace3_amd import SppmContext, scenes
