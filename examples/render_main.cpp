@@ -3,11 +3,13 @@
 // of the reference scene.  Writes the resolved flux image as raw doubles ([h][w][3]) so the
 // tests can compare it with the Python-driven path and the oracle.
 //
-//   render_main <out.f64> [w h rounds replica [stock]]
-// With a sixth argument the scene is the reference's own Scene::init() (textures: <name>.ppm next to the working
+//   render_main <out.f64> [w h rounds replica [stock | file.scene]]
+// With "stock" as sixth argument the scene is the reference's own Scene::init(), with a file name the scene file
+// is read by Scene::load() (textures: <name>.ppm next to the working
 // directory or in SPPM_DATA_DIR, procedural stand-ins otherwise).
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 #include "Camera.h"
 #include "Element.h"
@@ -30,8 +32,15 @@ int main(int argc, char** argv) {
     camera.lookAt(org + Vec3(0, 0.042612, -1), 1 / 1.);
 
     Scene scene;
-    if (argc > 6) {
+    if (argc > 6 && std::string(argv[6]) == "stock") {
         scene.init();
+    } else if (argc > 6) {
+        try {
+            scene.load(argv[6]);                   // a scene description file
+        } catch (const std::exception& e) {
+            std::fprintf(stderr, "%s\n", e.what());
+            return 1;
+        }
     } else {
     const Material WHITE_DIFF(Vec3(.75, .75, .75), Vec3(), Vec3(), 0);
     const Material MIRROR(Vec3(), Vec3(1, 1, 1) * .999, Vec3(), 0);

@@ -303,6 +303,99 @@ def scene_caustic():
     return s
 
 
+# ------------------------------------------------------------------ scene description files
+# The reference hard-codes its scene in Scene::init (raytracer/Scene.h:98-164).  A scene file says the same
+# things line by line, `keyword key=value ...`, vectors as comma lists, '#' starts a comment:
+#   material NAME [diff=r,g,b] [refl=r,g,b] [refr=r,g,b] [refrn=x] [refln=x]      Material(diff, refl, refr, refrn, refln)
+#   texture  NAME file=wall.ppm                                                    Texture("wall.ppm"); procedural stand-in if unreadable
+#   plane    p0=x,y,z n=x,y,z color=r,g,b material=NAME [texture=NAME]             PlaneObj(P0, n, color, material)
+#   sphere   radius=r center=x,y,z color=r,g,b material=NAME [texture=NAME]        SphereObj(radius, org, color, material)
+#   bezier   file=teapot.bpt center=x,y,z scale=s color=r,g,b material=NAME [texture=NAME] [trans=m00,...,m22]
+#                                                                                  Bezier3Obj(C, scale, file, color, material, Trans)
+#   light    pos=x,y,z color=r,g,b                                                 SpotLight(pos, color)
+# Files named in a scene file are looked up next to it, then in the data directory.  The C++ host reads the same
+# files with Scene::load (include/raytrace3/Scene.h).
+def _scene_tokens(path):
+    with open(path) as f:
+        for ln, line in enumerate(f, 1):
+            line = line.split("#", 1)[0].split()
+            if not line:
+                continue
+            kw, args, names = line[0], {}, []
+            for tok in line[1:]:
+                if "=" in tok:
+                    k, v = tok.split("=", 1)
+                    args[k] = v
+                else:
+                    names.append(tok)
+            yield ln, kw, names, args
+
+
+def load_scene(path, data_dir=None):
+    """Reads a scene description file into a FlatScene (see the format above)."""
+    here = os.path.dirname(os.path.abspath(path))
+    data_dir = data_dir or DATA_DIR
+
+    def find(name):
+        for d in (here, data_dir):
+            if os.path.exists(os.path.join(d, name)):
+                return os.path.join(d, name)
+        return None
+
+    def vec(text, n, what, ln):
+        v = [float(x) for x in text.split(",")]
+        if len(v) != n:
+            raise ValueError(f"{path}:{ln}: {what} needs {n} numbers")
+        return v
+
+    s, mats, texs = FlatScene(), {}, {}
+    for ln, kw, names, a in _scene_tokens(path):
+        def need(key):
+            if key not in a:
+                raise ValueError(f"{path}:{ln}: {kw} needs {key}=")
+            return a[key]
+
+        def tex_of():
+            if "texture" not in a:
+                return -1
+            if a["texture"] not in texs:
+                raise ValueError(f"{path}:{ln}: unknown texture {a['texture']}")
+            return texs[a["texture"]]
+
+        def mat_of():
+            if need("material") not in mats:
+                raise ValueError(f"{path}:{ln}: unknown material {a['material']}")
+            return mats[a["material"]]
+
+        if kw == "material":
+            if len(names) != 1:
+                raise ValueError(f"{path}:{ln}: material needs a name")
+            mats[names[0]] = material(vec(a.get("diff", "0,0,0"), 3, "diff", ln), vec(a.get("refl", "0,0,0"), 3, "refl", ln),
+                                      vec(a.get("refr", "0,0,0"), 3, "refr", ln), float(a.get("refrn", 1.5)), float(a.get("refln", 1.0)))
+        elif kw == "texture":
+            if len(names) != 1:
+                raise ValueError(f"{path}:{ln}: texture needs a name")
+            f = find(need("file"))
+            stem = os.path.splitext(os.path.basename(a["file"]))[0]
+            texs[names[0]] = s.add_texture(load_ppm(f) if f else procedural_texture(stem))
+        elif kw == "plane":
+            s.add_plane(vec(need("p0"), 3, "p0", ln), vec(need("n"), 3, "n", ln), vec(need("color"), 3, "color", ln), mat_of(), tex_of())
+        elif kw == "sphere":
+            s.add_sphere(float(need("radius")), vec(need("center"), 3, "center", ln), vec(need("color"), 3, "color", ln), mat_of(), tex_of())
+        elif kw == "bezier":
+            f = find(need("file"))
+            if not f:
+                raise ValueError(f"{path}:{ln}: cannot find {a['file']}")
+            trans = np.array(vec(a["trans"], 9, "trans", ln)).reshape(3, 3) if "trans" in a else None
+            s.add_bezier(vec(need("center"), 3, "center", ln), float(need("scale")), f, vec(need("color"), 3, "color", ln), mat_of(),
+                         trans, tex_of())
+        elif kw == "light":
+            s.add_light(vec(need("pos"), 3, "pos", ln), vec(need("color"), 3, "color", ln))
+        else:
+            raise ValueError(f"{path}:{ln}: unknown keyword {kw}")
+    return s
+
+
 # BASELINE.json configs: name -> (scene factory, (w, h), rounds, per_round)
 CONFIGS = {
     "c1_spheres_plane_256": (lambda: scene_spheres_plane(False), (256, 256), 1000, 100),

@@ -186,3 +186,36 @@ def _oracle_image(scene, cam, seed, replica):
     o.eye_pass(cam, seed, replica=replica)
     o.photon_pass(60, 100, seed, replica=replica)
     return o.resolve()
+
+
+@pytest.mark.gpu
+def test_scene_file_through_both_hosts(tmp_path):
+    """The same scene description file read by Scene::load (C++ host) and scenes.load_scene (ctypes host): one
+    picture.  The file is the four-teapot scene with PPM textures next to it."""
+    import shutil
+    from raytrace3_amd import SppmContext, scenes
+    rng = np.random.default_rng(9)
+    for name in ("timg", "wall", "planet", "blue"):
+        scenes.save_ppm(tmp_path / (name + ".ppm"), rng.integers(0, 256, size=(24, 32, 3), dtype=np.uint8))
+    shutil.copy(os.path.join(scenes.DATA_DIR, "four_teapots.scene"), tmp_path / "s.scene")
+    exe = os.path.join(ROOT, "examples", "_build", "render_main")
+    out = tmp_path / "pic.f64"
+    env = dict(os.environ, SPPM_SEED="79", SPPM_DATA_DIR=scenes.DATA_DIR)       # teapot.bpt comes from the data directory
+    r = subprocess.run([exe, str(out), "64", "48", "60", "2", str(tmp_path / "s.scene")], capture_output=True, text=True, env=env,
+                       timeout=120, cwd=str(tmp_path.parent))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "procedural" not in r.stderr and "12 objects" in r.stdout
+    cpp = np.fromfile(out, dtype=np.float64).reshape(48, 64, 3)
+    g = SppmContext(0)
+    g.set_scene(scenes.load_scene(str(tmp_path / "s.scene")))
+    g.eye_pass(scenes.default_camera(64, 48), 79, replica=2)
+    g.photon_pass(60, 100, 79, replica=2)
+    py = g.resolve()
+    g.close()
+    assert cpp.mean() > 0
+    assert np.allclose(cpp, py, rtol=1e-4, atol=1e-6 * py.mean())
+    # a line the format does not know stops the C++ host with the file name and line number
+    (tmp_path / "bad.scene").write_text("material M diff=1,1,1\ncube size=1\n")
+    bad = subprocess.run([exe, str(out), "8", "8", "1", "0", str(tmp_path / "bad.scene")], capture_output=True, text=True, env=env,
+                         timeout=120)
+    assert bad.returncode != 0 and "bad.scene:2: unknown keyword cube" in bad.stderr
