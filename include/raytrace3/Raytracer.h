@@ -12,6 +12,8 @@
 //   SPPM_DEVICES  comma-separated GPU ids, one library context (= HIP stream) per entry; the four
 //                 replicas of an iteration are dealt over them.  Default "0,0": two contexts on GPU 0,
 //                 so the eye pass of one replica overlaps the photon pass of another.
+//   SPPM_INITIAL_N / SPPM_UPDATE_ROUNDS   HitPoints start with this N (0: the reference, whose update() then never runs) and,
+//                 if positive, update() runs after every SPPM_UPDATE_ROUNDS rounds (1) — sppm_set_radius_update
 //   SPPM_SAVE_EVERY        write the running mean every n-th outer iteration (1, as the reference) and after the last
 //   SPPM_CHECKPOINT        file that receives the fp64 image sum, the iteration count and the jitter generator's state
 //   SPPM_CHECKPOINT_EVERY  ... every n-th outer iteration (10) and after the last
@@ -216,6 +218,8 @@ private:
     void eye_locked(sppm_host::Device& dev) {
         if (!camera || !scene) throw std::runtime_error("RayTracer: camera and scene must be set");
         dev.ensure_scene(scene->objvec, scene->plvec);
+        dev.check(sppm_set_radius_update(dev.ctx, (int32_t)sppm_host::env_ll("SPPM_INITIAL_N", 0), (uint32_t)sppm_host::env_ll("SPPM_UPDATE_ROUNDS", 1)),
+                  "sppm_set_radius_update");
         sppm_camera c;
         for (int k = 0; k < 3; k++) { c.pos[k] = camera->pos.val[k]; c.dir[k] = camera->dir.val[k]; c.du[k] = camera->du.val[k]; c.dv[k] = camera->dv.val[k]; }
         c.w = camera->w; c.h = camera->h;

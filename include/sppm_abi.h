@@ -224,6 +224,16 @@ int sppm_synchronize(sppm_ctx* ctx);
  * of waiting for the stream after each); accumulate = 0 clears them and restores the default. */
 int sppm_stats_mode(sppm_ctx* ctx, int accumulate);
 
+/* The progressive radius update, HitPoint::update (raytracer/Raytracer.h:69-79) swept over all HitPoints after
+ * every round of PhotonMap (:237-245).  As written in the reference it never runs: N starts at 0 and the guard
+ * `if (N <= 0 || newN <= 0) return;` leaves at once, so radii stay at INIT_R2 — and that is this library's
+ * default (initial_n = 0).  initial_n > 0 is a DEVIATION offered as a knob: HitPoints of the following eye passes
+ * start with that N, and sppm_photon_pass then runs update() exactly as written after every
+ * rounds_per_update rounds (the reference's cadence is 1; larger values trade fidelity for larger batches).
+ * R2 only shrinks, the search radius stays INIT_R2 (updateR2 is commented out, Raytracer.h:246).  A pass with the
+ * update on cannot be sharded by photon range: each update needs all photons of its rounds. */
+int sppm_set_radius_update(sppm_ctx* ctx, int32_t initial_n, uint32_t rounds_per_update);
+
 /* A context queues its work on a HIP stream of its own.  sppm_set_stream makes it use the caller's stream
  * (a hipStream_t of the context's GPU; NULL: back to its own) from the next call on, after waiting for what it
  * had queued so far, so that a host can order the library's passes with its own GPU work (a collective on the

@@ -410,6 +410,10 @@ struct oracle_ctx {
     std::vector<HitPoint> Hvec;
     sppm_counters cnt{};
     uint64_t last_rounds = 0, last_per_round = 0;
+    // The radius-update knob of the GPU library (sppm_set_radius_update), restated: HitPoints start with initial_n
+    // instead of 0, and the sweep of Raytracer.h:237-245 runs after every rounds_per_update rounds.
+    int initial_n = 0;
+    uint32_t rounds_per_update = 1;
     // exact uniform grid over HitPoints
     std::unordered_map<uint64_t, std::vector<int>> grid;
     // kd-tree
@@ -562,6 +566,7 @@ struct oracle_ctx {
             HitPoint hp;
             hp.pos = c1.Pos; hp.n = c1.N; hp.v = c1.From; hp.obj = c1.obj; hp.x = x; hp.y = y; hp.node = (int)node;
             hp.wgt = mul(mul(c1.color, wgt), obj.material.diff);
+            hp.N = initial_n;
             Hvec.push_back(hp);
         }
         if (obj.material.IsRefl()) {
@@ -719,7 +724,8 @@ struct oracle_ctx {
             emit(l, rnd, org, dir, flux);
             cnt.photons++;
             PhotonTrace(org, dir, flux, seed, replica, (uint32_t)g, deposit);
-            if (sweep && per && ((g + 1) % per == 0)) {                  // Raytracer.h:237-245
+            const uint64_t cadence = initial_n > 0 ? per * rounds_per_update : per;
+            if ((sweep || initial_n > 0) && cadence && ((g + 1) % cadence == 0 || (initial_n > 0 && g + 1 == end))) {   // Raytracer.h:237-245
                 double maxr2 = 0;
                 for (auto& hp : Hvec) {
                     hp.update();
@@ -736,6 +742,13 @@ static V3 v3(const double* p) { return V3(p[0], p[1], p[2]); }
 static void put3(double* o, const V3& v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
 
 extern "C" {
+
+int oracle_set_radius_update(oracle_ctx* ctx, int32_t initial_n, uint32_t rounds_per_update) {
+    if (!ctx || initial_n < 0 || (initial_n > 0 && rounds_per_update == 0)) return SPPM_E_INVALID;
+    ctx->initial_n = initial_n;
+    ctx->rounds_per_update = rounds_per_update ? rounds_per_update : 1;
+    return SPPM_OK;
+}
 
 oracle_ctx* oracle_create(int newton_fp32, int rng_literal) {
     oracle_ctx* c = new oracle_ctx();

@@ -29,6 +29,8 @@ typedef struct oracle_ctx oracle_ctx;
  *              path reproduces draw for draw. */
 oracle_ctx* oracle_create(int newton_fp32, int rng_literal);
 void oracle_destroy(oracle_ctx* ctx);
+/* The radius-update knob of sppm_set_radius_update restated (initial_n = 0: the reference's dead update()). */
+int oracle_set_radius_update(oracle_ctx* ctx, int32_t initial_n, uint32_t rounds_per_update);
 
 int oracle_set_scene(oracle_ctx* ctx, const sppm_scene* scene);
 int oracle_eye_pass(oracle_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t replica);

@@ -104,6 +104,7 @@ ABI_SYMBOLS = {
     "sppm_film_tonemap": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_void_p]),
     "sppm_film_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "sppm_film_write": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "sppm_set_radius_update": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint32]),
     "sppm_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sppm_get_stream": (C.c_void_p, [C.c_void_p]),
     "sppm_synchronize": (C.c_int, [C.c_void_p]),
@@ -206,6 +207,11 @@ class SppmContext:
     def synchronize(self):
         """Wait for the queued passes; raises if one of them overflowed a queue."""
         self._check(self.lib.sppm_synchronize(self._ctx), "sppm_synchronize")
+
+    def set_radius_update(self, initial_n, rounds_per_update=1):
+        """initial_n > 0: HitPoints start with that N and HitPoint::update() runs after every rounds_per_update
+        rounds of a photon pass (a deviation from the reference, where N = 0 keeps it from running); 0: off."""
+        self._check(self.lib.sppm_set_radius_update(self._ctx, int(initial_n), int(rounds_per_update)), "sppm_set_radius_update")
 
     def set_stream(self, hip_stream):
         """Queue this context's passes on the caller's HIP stream (an integer handle such as

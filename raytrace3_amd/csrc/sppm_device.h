@@ -23,6 +23,7 @@ namespace sppm {
 #define SPPM_MAX_NUM 1e20
 #define SPPM_MAX_DEP 13
 #define SPPM_INIT_R2 2.0
+#define SPPM_ALPHA 0.7          // Raytracer.h:45
 #define SPPM_NEWTON_ITERS 10
 #define SPPM_NEWTON_RESTARTS 50
 

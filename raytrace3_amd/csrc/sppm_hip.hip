@@ -671,7 +671,8 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_final(const uint32_t* __r
 }
 
 __global__ void k_hp_scatter(const RawHit* hits, uint32_t n, GridParams g, const uint32_t* bucket_of, const uint32_t* start,
-                             uint32_t* cursor, PosKey* hp_pos, float4* hp_nr, float4* hp_wgt, float4* hp_tao, HpMeta* hp_meta) {
+                             uint32_t* cursor, PosKey* hp_pos, float4* hp_nr, float4* hp_wgt, float4* hp_tao, HpMeta* hp_meta,
+                             double* hp_r2, int initial_n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t b = bucket_of[i];
@@ -680,10 +681,11 @@ __global__ void k_hp_scatter(const RawHit* hits, uint32_t n, GridParams g, const
     uint32_t s = start[b] + atomicAdd(&cursor[b], 1u);
     PosKey pk; pk.x = h.pos[0]; pk.y = h.pos[1]; pk.z = h.pos[2]; pk.key = cell_key(ld3(h.pos), g.inv_cs);
     hp_pos[s] = pk;
-    hp_nr[s] = make_float4(h.n[0], h.n[1], h.n[2], (float)SPPM_INIT_R2);                  // HitPoint(): R2 = INIT_R2, Raytracer.h:65
+    hp_nr[s] = make_float4(h.n[0], h.n[1], h.n[2], 0.f);
+    hp_r2[s] = SPPM_INIT_R2;                                                              // HitPoint(): R2 = INIT_R2, Raytracer.h:65
     hp_wgt[s] = make_float4(h.wgt[0], h.wgt[1], h.wgt[2], __int_as_float(h.pix));
     hp_tao[s] = make_float4(0, 0, 0, __int_as_float(0));                                  // tao = 0, newN = 0
-    HpMeta m; m.v[0] = h.v[0]; m.v[1] = h.v[1]; m.v[2] = h.v[2]; m.node = h.node; m.obj = h.obj; m.N = 0;
+    HpMeta m; m.v[0] = h.v[0]; m.v[1] = h.v[1]; m.v[2] = h.v[2]; m.node = h.node; m.obj = h.obj; m.N = initial_n;   // HitPoint(): N = 0, Raytracer.h:66
     hp_meta[s] = m;
 }
 
@@ -702,6 +704,23 @@ __global__ void k_hp_occupancy(const PosKey* __restrict__ hp_pos, uint32_t n, Gr
         const uint64_t nb_key = key + ((uint64_t)(int64_t)dx << 42) + ((uint64_t)(int64_t)dy << 21) + (uint64_t)(int64_t)dz;
         occ[key_bucket(nb_key, g.mask)] = 1;
     }
+}
+
+// HitPoint::update (Raytracer.h:69-79) for every HitPoint, the sweep of Raytracer.h:237-245.  With N = 0, the
+// reference's initial value, the guard returns at once; the sweep is only launched when a host asked for another
+// initial N (sppm_set_radius_update).
+__global__ void k_hp_update(double* hp_r2, float4* hp_tao, HpMeta* hp_meta, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 t = hp_tao[i];
+    const int N = hp_meta[i].N, newN = __float_as_int(t.w);
+    if (N <= 0 || newN <= 0) return;
+    const double k = (N + SPPM_ALPHA * newN) / (N + newN);
+    hp_r2[i] *= k;
+    t.x = (float)(t.x * k); t.y = (float)(t.y * k); t.z = (float)(t.z * k);
+    t.w = __int_as_float(0);
+    hp_tao[i] = t;
+    hp_meta[i].N = (int)(N + SPPM_ALPHA * newN);          // `N += alpha * newN` on an int
 }
 
 __global__ void k_dep_scatter(const Deposit* __restrict__ dep, const unsigned long long* n_dep, unsigned long long cap,
@@ -774,6 +793,7 @@ struct GatherPiece { uint32_t tile_base, lead, row_begin, row_end; };   // lead:
 
 template <bool PIECE>
 __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
+                                            const double* __restrict__ hp_r2,
                                             const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, const uint32_t n_hp,
                                             const uint32_t* __restrict__ dstart, const Deposit* __restrict__ deps,
                                             const GridParams g, GatherPiece* __restrict__ pieces, unsigned long long* n_pieces,
@@ -784,6 +804,7 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
     const bool valid = (uint32_t)lane < GATHER_TILE && mine < n_hp;
     const PosKey mp = hp_pos[valid ? mine : base];
     const float4 mnr = hp_nr[valid ? mine : base];
+    const double mr2 = hp_r2[valid ? mine : base];
     const float4 mw = hp_wgt[valid ? mine : base];
     float tr = 0, tg = 0, tb = 0;
     uint32_t tn = 0;
@@ -863,7 +884,7 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
                 gm &= gm - 1;
                 const double hx = bcast_d(mp.x, j), hy = bcast_d(mp.y, j), hz = bcast_d(mp.z, j);
                 const float nx = bcast_f(mnr.x, j), ny = bcast_f(mnr.y, j), nz = bcast_f(mnr.z, j);
-                const double R2 = (double)bcast_f(mnr.w, j);
+                const double R2 = bcast_d(mr2, j);
                 const float wr = bcast_f(mw.x, j), wg = bcast_f(mw.y, j), wb = bcast_f(mw.z, j);
                 float pr = 0, pg = 0, pb = 0;
                 uint32_t pn = 0;
@@ -933,7 +954,7 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
 // tiles in flight on one XCD are neighbours in bucket order and share its L2, and moves on to the
 // other eighths when its own is drained (tile cost varies with the photon density around it).
 __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
-                                                const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
+                                                const double* __restrict__ hp_r2, const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
                                                 const uint32_t* __restrict__ dstart, const Deposit* __restrict__ deps,
                                                 GridParams g, uint32_t* tile_ctr, GatherPiece* __restrict__ pieces,
                                                 unsigned long long* n_pieces, uint32_t piece_cap, DevCounters* counters) {
@@ -948,7 +969,7 @@ __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_po
             if (lane_id() == 0) t = atomicAdd(&tile_ctr[q * 16], 1u);
             t = bcast_u(t, 0) + q * per;
             if (t >= q_end) break;
-            gather_tile<false>(t * GATHER_TILE, hp_pos, hp_nr, hp_wgt, hp_tao, n_hp, dstart, deps, g, pieces, n_pieces, piece_cap,
+            gather_tile<false>(t * GATHER_TILE, hp_pos, hp_nr, hp_r2, hp_wgt, hp_tao, n_hp, dstart, deps, g, pieces, n_pieces, piece_cap,
                                &counters->overflow, GatherPiece{0, 0, 0, 0}, cand, acc_n);
         }
     }
@@ -960,7 +981,7 @@ __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_po
 
 // The queued pieces of heavy cells (see GATHER_SPLIT_ROWS), one wave per piece at a time.
 __global__ void __launch_bounds__(256) k_gather_split(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
-                                                      const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
+                                                      const double* __restrict__ hp_r2, const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
                                                       const uint32_t* __restrict__ dstart, const Deposit* __restrict__ deps, GridParams g,
                                                       const GatherPiece* __restrict__ pieces, const unsigned long long* __restrict__ n_pieces,
                                                       uint32_t piece_cap, unsigned long long* next_piece, DevCounters* counters) {
@@ -971,7 +992,7 @@ __global__ void __launch_bounds__(256) k_gather_split(const PosKey* __restrict__
     // play (a launch with nothing queued costs no atomic at all)
     for (unsigned long long i = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n;) {
         const GatherPiece pc = pieces[i];
-        gather_tile<true>(pc.tile_base, hp_pos, hp_nr, hp_wgt, hp_tao, n_hp, dstart, deps, g, nullptr, nullptr, 0u, nullptr, pc, cand, acc_n);
+        gather_tile<true>(pc.tile_base, hp_pos, hp_nr, hp_r2, hp_wgt, hp_tao, n_hp, dstart, deps, g, nullptr, nullptr, 0u, nullptr, pc, cand, acc_n);
         if (n <= n_waves) break;
         unsigned long long nx = 0;
         if (lane_id() == 0) nx = atomicAdd(next_piece, 1ull);
@@ -984,12 +1005,12 @@ __global__ void __launch_bounds__(256) k_gather_split(const PosKey* __restrict__
 }
 
 // ------------------------------------------------------------------ resolve (Raytracer.h:281-293)
-__global__ void k_resolve(const float4* hp_nr, const float4* hp_wgt, const float4* hp_tao, uint32_t n_hp, double inv_norm, float* pic) {
+__global__ void k_resolve(const double* hp_r2, const float4* hp_wgt, const float4* hp_tao, uint32_t n_hp, double inv_norm, float* pic) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_hp) return;
     float4 t = hp_tao[i];
     int pix = __float_as_int(hp_wgt[i].w);
-    double s = inv_norm / (double)hp_nr[i].w;   // 1 / PI / (R2 * cnt * onetime)
+    double s = inv_norm / hp_r2[i];   // 1 / PI / (R2 * cnt * onetime)
     atomicAdd(&pic[3 * (size_t)pix + 0], (float)(t.x * s));
     atomicAdd(&pic[3 * (size_t)pix + 1], (float)(t.y * s));
     atomicAdd(&pic[3 * (size_t)pix + 2], (float)(t.z * s));
@@ -998,13 +1019,13 @@ __global__ void k_resolve(const float4* hp_nr, const float4* hp_wgt, const float
 // ------------------------------------------------------------------ film: image sum and tone-map (Raytracer.h:449-470)
 // film += resolve: the image sum of SPPMRayTracer::render (Raytracer.h:449-458) taken straight from the HitPoints, in fp64
 // as the reference's camera.pic.  Contexts on other streams add to the same film, hence the atomics.
-__global__ void k_film_add(const float4* hp_nr, const float4* hp_wgt, const float4* hp_tao, uint32_t n_hp, double inv_norm, double* film) {
+__global__ void k_film_add(const double* hp_r2, const float4* hp_wgt, const float4* hp_tao, uint32_t n_hp, double inv_norm, double* film) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_hp) return;
     float4 t = hp_tao[i];
     if (t.x == 0.f && t.y == 0.f && t.z == 0.f) return;
     int pix = __float_as_int(hp_wgt[i].w);
-    double s = inv_norm / (double)hp_nr[i].w;   // 1 / PI / (R2 * cnt * onetime)
+    double s = inv_norm / hp_r2[i];   // 1 / PI / (R2 * cnt * onetime)
     unsafeAtomicAdd(&film[3 * (size_t)pix + 0], (double)t.x * s);
     unsafeAtomicAdd(&film[3 * (size_t)pix + 1], (double)t.y * s);
     unsafeAtomicAdd(&film[3 * (size_t)pix + 2], (double)t.z * s);
@@ -1146,7 +1167,9 @@ struct sppm_ctx {
     uint32_t* dcount() const { return hcount() + 2 * ((size_t)grid.mask + 2); }
     bool dep_filter = true;               // deposits no HitPoint can reach are not stored (SPPM_DEP_FILTER=0 keeps them)
     bool has_dual_lobe = false;           // some material reflects and refracts: eye paths branch
-    DevBuf<PosKey> hp_pos; DevBuf<float4> hp_nr, hp_wgt, hp_tao; DevBuf<HpMeta> hp_meta;
+    DevBuf<PosKey> hp_pos; DevBuf<float4> hp_nr, hp_wgt, hp_tao; DevBuf<HpMeta> hp_meta; DevBuf<double> hp_r2;
+    int initial_n = 0;                    // HitPoint::N at creation (the reference: 0, which keeps update() from ever running)
+    uint32_t rounds_per_update = 1;       // with initial_n > 0: rounds of a photon pass between two update() sweeps
     uint64_t n_hp = 0;
     GridParams grid{};
     // photon pass
@@ -1282,7 +1305,7 @@ void sppm_destroy(sppm_ctx* ctx) {
     ctx->blob.release(); ctx->tex.release(); ctx->texels.release(); ctx->lights.release();
     ctx->raw.release(); ctx->park[0].release(); ctx->park[1].release(); ctx->ntask[0].release(); ctx->ntask[1].release(); ctx->nres.release();
     ctx->bucket_of.release(); ctx->hist.release(); ctx->hstart.release();
-    ctx->hp_pos.release(); ctx->hp_nr.release(); ctx->hp_wgt.release(); ctx->hp_tao.release(); ctx->hp_meta.release();
+    ctx->hp_pos.release(); ctx->hp_nr.release(); ctx->hp_wgt.release(); ctx->hp_tao.release(); ctx->hp_meta.release(); ctx->hp_r2.release();
     ctx->dep.release(); ctx->sdep.release(); ctx->pieces.release();
     ctx->dstart.release(); ctx->scan_partial.release(); ctx->ctl.release(); ctx->counters.release(); ctx->pic.release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -1653,14 +1676,15 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
     HIPCHK(ctx->hstart.reserve(M + 1)); HIPCHK(ctx->dstart.reserve(M + 1));
     HIPCHK(ctx->hp_pos.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_nr.reserve(std::max<uint64_t>(n, 1)));
     HIPCHK(ctx->hp_wgt.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_tao.reserve(std::max<uint64_t>(n, 1)));
-    HIPCHK(ctx->hp_meta.reserve(std::max<uint64_t>(n, 1)));
+    HIPCHK(ctx->hp_meta.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_r2.reserve(std::max<uint64_t>(n, 1)));
     if (int rc = launch_fill(ctx, hist_words(ctx), ctx->occ_words() + 2 * ((size_t)M + 1), 0)) return rc;   // occupancy, hcount, cursor
     if (n > 0) {
         const int blocks = (int)((claimed + 255) / 256);
         hipLaunchKernelGGL(k_hp_count, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)claimed, ctx->grid, ctx->bucket_of.p, ctx->hcount());
         if (int rc = launch_scan(ctx, ctx->hcount(), ctx->hstart.p, M)) return rc;
         hipLaunchKernelGGL(k_hp_scatter, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)claimed, ctx->grid, ctx->bucket_of.p,
-                           ctx->hstart.p, ctx->cursor(), ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->hp_tao.p, ctx->hp_meta.p);
+                           ctx->hstart.p, ctx->cursor(), ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->hp_tao.p, ctx->hp_meta.p,
+                           ctx->hp_r2.p, ctx->initial_n);
         hipLaunchKernelGGL(k_hp_occupancy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->hp_pos.p, (uint32_t)n, ctx->grid, ctx->occ());
         HIPCHK(hipGetLastError());
     }
@@ -1708,6 +1732,14 @@ int sppm_set_stream(sppm_ctx* ctx, void* hip_stream) {
     return SPPM_OK;
 }
 
+int sppm_set_radius_update(sppm_ctx* ctx, int32_t initial_n, uint32_t rounds_per_update) {
+    if (!ctx) return SPPM_E_INVALID;
+    if (initial_n < 0 || (initial_n > 0 && rounds_per_update == 0)) return fail(ctx, SPPM_E_INVALID, "initial_n >= 0 and rounds_per_update >= 1");
+    ctx->initial_n = initial_n;
+    ctx->rounds_per_update = std::max<uint32_t>(1, rounds_per_update);
+    return SPPM_OK;
+}
+
 void* sppm_get_stream(const sppm_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 int sppm_synchronize(sppm_ctx* ctx) {
@@ -1730,7 +1762,14 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
     const uint64_t end = photon_count == 0 ? total : std::min(total, photon_begin + photon_count);
     ctx->last_rounds = rounds; ctx->last_per_round = per_round;
     const uint32_t M = ctx->grid.mask + 1;
-    const uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(ctx->batch, end > photon_begin ? end - photon_begin : 1));
+    uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(ctx->batch, end > photon_begin ? end - photon_begin : 1));
+    const bool sweeps = ctx->initial_n > 0;      // HitPoint::update() after every rounds_per_update rounds (Raytracer.h:237-245)
+    if (sweeps) {
+        if (photon_begin != 0 || end != total)
+            return fail(ctx, SPPM_E_INVALID, "with the radius update on, a photon pass cannot be sharded: every update needs all photons of its rounds");
+        batch = (uint64_t)ctx->rounds_per_update * ctx->n_lights * per_round;
+        if (batch > (1ull << 24)) return fail(ctx, SPPM_E_INVALID, "more than 2^24 photons between two radius updates");
+    }
     const uint64_t dep_cap = batch * (SPPM_MAX_DEP + 1) + dep_slack(ctx);
     HIPCHK(ctx->dep.reserve(dep_cap)); HIPCHK(ctx->sdep.reserve(dep_cap));
     TraceParams tp{};
@@ -1757,15 +1796,20 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
             const int blocks = (int)std::max<uint64_t>(8, std::min<uint64_t>((uint64_t)ctx->num_cu * ctx->gather_blocks_per_cu, ((tiles + 3) / 4 + 7) / 8 * 8));
             const uint32_t piece_cap = 1u << 20;
             HIPCHK(ctx->pieces.reserve(piece_cap));
-            hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->hp_tao.p,
+            hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_r2.p, ctx->hp_wgt.p, ctx->hp_tao.p,
                                (uint32_t)ctx->n_hp, ctx->dstart.p, ctx->sdep.p, ctx->grid, ctx->tile_ctr(), ctx->pieces.p,
                                ctx->scalars() + SC_PIECES, piece_cap, ctx->counters.p);
-            hipLaunchKernelGGL(k_gather_split, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p,
+            hipLaunchKernelGGL(k_gather_split, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_r2.p, ctx->hp_wgt.p,
                                ctx->hp_tao.p, (uint32_t)ctx->n_hp, ctx->dstart.p, ctx->sdep.p, ctx->grid, ctx->pieces.p,
                                ctx->scalars() + SC_PIECES, piece_cap, ctx->scalars() + SC_NEXT_PIECE, ctx->counters.p);
             HIPCHK(hipGetLastError());
             toc(ctx);
             ctx->gather_launches++;
+            if (sweeps) {
+                hipLaunchKernelGGL(k_hp_update, dim3((unsigned)((ctx->n_hp + 255) / 256)), dim3(256), 0, ctx->stream, ctx->hp_r2.p, ctx->hp_tao.p,
+                                   ctx->hp_meta.p, (uint32_t)ctx->n_hp);
+                HIPCHK(hipGetLastError());
+            }
         }
     }
     return SPPM_OK;   // queued; a queue overflow, if any, is reported by the next call that waits for the stream
@@ -1782,7 +1826,7 @@ int sppm_resolve_device(sppm_ctx* ctx, float* dev_pic) {
     if (ctx->n_hp > 0) {
         const double inv_norm = 1.0 / SPPM_PI / ((double)ctx->last_rounds * (double)ctx->last_per_round);
         const int blocks = (int)((ctx->n_hp + 255) / 256);
-        hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->hp_tao.p, (uint32_t)ctx->n_hp,
+        hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_r2.p, ctx->hp_wgt.p, ctx->hp_tao.p, (uint32_t)ctx->n_hp,
                            inv_norm, dev_pic);
         HIPCHK(hipGetLastError());
     }
@@ -1813,7 +1857,9 @@ int sppm_get_hitpoints(sppm_ctx* ctx, sppm_hitpoint* out, uint64_t cap, uint64_t
     const uint64_t m = std::min<uint64_t>(cap, ctx->n_hp);
     if (m == 0 || !out) return SPPM_OK;
     HIPCHK(hipSetDevice(ctx->device));
-    std::vector<PosKey> pos(m); std::vector<float4> nr(m), wg(m), tao(m); std::vector<HpMeta> meta(m);
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // the copies below go through the null stream, which a caller's stream need not wait for
+    std::vector<PosKey> pos(m); std::vector<float4> nr(m), wg(m), tao(m); std::vector<HpMeta> meta(m); std::vector<double> r2(m);
+    HIPCHK(hipMemcpy(r2.data(), ctx->hp_r2.p, m * sizeof(double), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(pos.data(), ctx->hp_pos.p, m * sizeof(PosKey), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(nr.data(), ctx->hp_nr.p, m * sizeof(float4), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(wg.data(), ctx->hp_wgt.p, m * sizeof(float4), hipMemcpyDeviceToHost));
@@ -1822,7 +1868,7 @@ int sppm_get_hitpoints(sppm_ctx* ctx, sppm_hitpoint* out, uint64_t cap, uint64_t
     for (uint64_t i = 0; i < m; i++) {
         sppm_hitpoint& h = out[i];
         h.pos[0] = pos[i].x; h.pos[1] = pos[i].y; h.pos[2] = pos[i].z;
-        h.n[0] = nr[i].x; h.n[1] = nr[i].y; h.n[2] = nr[i].z; h.R2 = nr[i].w;
+        h.n[0] = nr[i].x; h.n[1] = nr[i].y; h.n[2] = nr[i].z; h.R2 = r2[i];
         h.v[0] = meta[i].v[0]; h.v[1] = meta[i].v[1]; h.v[2] = meta[i].v[2];
         h.wgt[0] = wg[i].x; h.wgt[1] = wg[i].y; h.wgt[2] = wg[i].z;
         h.tao[0] = tao[i].x; h.tao[1] = tao[i].y; h.tao[2] = tao[i].z;
@@ -2074,7 +2120,7 @@ int sppm_film_add(sppm_ctx* ctx, sppm_film* film) {
     tic(ctx, PH_RESOLVE);
     if (ctx->n_hp > 0) {
         const double inv_norm = 1.0 / SPPM_PI / ((double)ctx->last_rounds * (double)ctx->last_per_round);
-        hipLaunchKernelGGL(k_film_add, dim3((unsigned)((ctx->n_hp + 255) / 256)), dim3(256), 0, ctx->stream, ctx->hp_nr.p, ctx->hp_wgt.p,
+        hipLaunchKernelGGL(k_film_add, dim3((unsigned)((ctx->n_hp + 255) / 256)), dim3(256), 0, ctx->stream, ctx->hp_r2.p, ctx->hp_wgt.p,
                            ctx->hp_tao.p, (uint32_t)ctx->n_hp, inv_norm, film->acc.p);
         HIPCHK(hipGetLastError());
     }

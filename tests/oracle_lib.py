@@ -21,6 +21,7 @@ _D = C.POINTER(C.c_double)
 SYMBOLS = {
     "oracle_create": (C.c_void_p, [C.c_int, C.c_int]),
     "oracle_destroy": (None, [C.c_void_p]),
+    "oracle_set_radius_update": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint32]),
     "oracle_set_scene": (C.c_int, [C.c_void_p, C.POINTER(abi.Scene)]),
     "oracle_eye_pass": (C.c_int, [C.c_void_p, C.POINTER(abi.Camera), C.c_uint64, C.c_uint32]),
     "oracle_photon_pass": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int]),
@@ -85,6 +86,9 @@ class OracleContext:
             self.close()
         except Exception:
             pass
+
+    def set_radius_update(self, initial_n, rounds_per_update=1):
+        assert self.lib.oracle_set_radius_update(self._ctx, int(initial_n), int(rounds_per_update)) == 0
 
     def set_scene(self, scene):
         self._keep = scene

@@ -297,3 +297,41 @@ def test_paths_stop_at_the_depth_limit(gpu):
         _image_parity(gpu.resolve(), o.resolve(), frac=0.995)
     # a mirror-only eye path: 14 segments and no HitPoint
     assert co["eye_segments"] >= 14
+
+
+# ------------------------------------------------------------------ the radius-update knob
+def test_radius_update_knob_against_oracle(gpu):
+    """sppm_set_radius_update: HitPoints start at N = 1 and HitPoint::update() (Raytracer.h:69-79) runs after every
+    5 rounds.  N and R2 follow from integer photon counts through fp64 arithmetic: equal to the oracle's exactly
+    (R2 to the last bits); the fluxes to the fp32 tolerance of the other tests.  Off (the default), N stays 0 and
+    R2 stays INIT_R2."""
+    from raytrace3_amd import SppmError
+    scene, cam = scenes.scene_spheres_plane(True), scenes.default_camera(64, 48)
+    gpu.set_scene(scene)
+    o = _oracle(scene)
+    try:
+        gpu.set_radius_update(1, 5)
+        o.set_radius_update(1, 5)
+        gpu.eye_pass(cam, SEED)
+        o.eye_pass(cam, SEED)
+        gpu.photon_pass(203, 100, SEED)          # 41 sweeps, the last after 3 rounds
+        o.photon_pass(203, 100, SEED)
+        assert gpu.timings()["gather_launches"] == 41
+        g, c, n = _match(gpu.hitpoints(), o.hitpoints())
+        assert n == len(o.hitpoints()) == len(gpu.hitpoints())
+        assert np.array_equal(g["N"], c["N"]) and g["N"].max() > 1
+        assert not g["newN"].any() and not c["newN"].any()
+        assert np.allclose(g["R2"], c["R2"], rtol=1e-13, atol=0) and g["R2"].min() < 1.0 and g["R2"].max() <= 2.0
+        assert np.allclose(g["tao"], c["tao"], rtol=2e-4, atol=1e-6 * c["tao"].mean())
+        assert gpu.counters()["accepted"] == o.counters()["accepted"]
+        _image_parity(gpu.resolve(), o.resolve(), 0.995)
+        with pytest.raises(SppmError):
+            gpu.photon_pass(203, 100, SEED, photon_begin=0, photon_count=1000)    # a shard cannot update
+        with pytest.raises(SppmError):
+            gpu.set_radius_update(-1, 1)
+    finally:
+        gpu.set_radius_update(0)
+    gpu.eye_pass(cam, SEED)
+    gpu.photon_pass(20, 100, SEED)
+    hp = gpu.hitpoints()
+    assert not hp["N"].any() and np.all(hp["R2"] == 2.0) and hp["newN"].sum() == gpu.counters()["accepted"]
