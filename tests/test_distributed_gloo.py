@@ -103,3 +103,42 @@ def test_two_rank_sharded_iteration_on_the_gpu(tmp_path):
     assert full.sum() > 0
     # the same deposits, gathered in two shards and summed in fp32
     assert np.allclose(reduced, full, rtol=2e-4, atol=1e-6 * full.mean())
+
+
+@pytest.mark.gpu
+def test_all_reduce_ordered_by_the_contexts_stream():
+    """What bench.py does on N GPUs, with the one rank this box has: the flux image is resolved on the context's
+    own stream and all-reduced by RCCL (backend "nccl") under torch's handle of that stream, with no host-side
+    wait between the two; two contexts alternate as in the benchmark.  The reduced images are the resolved ones."""
+    from raytrace3_amd import SppmContext
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    ctxs = [SppmContext(0), SppmContext(0)]
+    try:
+        scene, cam = scenes.scene_teapot(1), scenes.default_camera(96, 72)
+        streams = [torch.cuda.ExternalStream(c.stream_handle()) for c in ctxs]
+        pics = [torch.zeros((72, 96, 3), dtype=torch.float32, device="cuda") for _ in ctxs]
+        for c in ctxs:
+            c.set_scene(scene)
+        for i in range(6):
+            k = i % 2
+            # world = 2 would shard the photons; the collective path is taken by hand here with the whole pass
+            ctxs[k].eye_pass(cam, SEED, i)
+            ctxs[k].photon_pass(ROUNDS, PER_ROUND, SEED, i)
+            ctxs[k].resolve_device(pics[k].data_ptr())
+            with torch.cuda.stream(streams[k]):
+                dist.all_reduce(pics[k], op=dist.ReduceOp.SUM)
+        for c in ctxs:
+            c.synchronize()
+        torch.cuda.synchronize()
+        for k, replica in ((0, 4), (1, 5)):
+            ctxs[k].eye_pass(cam, SEED, replica)
+            ctxs[k].photon_pass(ROUNDS, PER_ROUND, SEED, replica)
+            want = ctxs[k].resolve()
+            assert want.sum() > 0
+            assert np.allclose(pics[k].cpu().numpy(), want, rtol=2e-4, atol=1e-6 * want.mean())
+    finally:
+        for c in ctxs:
+            c.close()
+        dist.destroy_process_group()
