@@ -45,7 +45,9 @@ struct DevObject {
     float refl[3];
     float refr[3];
     int type, texture, first_patch, n_patches;
-    int flags, pad;
+    int flags;
+    int tex_rows, tex_cols;     // the object's texture, copied here so that a lookup starts from LDS (texture < 0: unused)
+    unsigned tex_off;           // first texel in the packed uchar4 array
 };
 
 struct TexDesc {
@@ -72,7 +74,6 @@ struct SceneView {
     const int* patch_obj;       // LDS, n_patches: owning object of each patch
     int n_objs;
     int n_patches;
-    const TexDesc* tex;         // global
     const uchar4* texels;       // global
 };
 
@@ -179,6 +180,11 @@ __device__ __forceinline__ d3 refracted(d3 I, d3 N, double n) {                 
     double cosI = -dot(N, I);
     double cosR2 = 1 - (1 - cosI * cosI) * (n * n);
     return (cosR2 > SPPM_EPS) ? I * n + N * (n * cosI - sqrt(cosR2)) : get_refl(I, N);
+}
+
+__device__ __forceinline__ TexDesc tex_of(const DevObject& ob) {
+    TexDesc t; t.rows = ob.tex_rows; t.cols = ob.tex_cols; t.offset = ob.tex_off; t.pad = 0;
+    return t;
 }
 
 // ------------------------------------------------------------------ Element.h:61-72 Texture::colorUV
@@ -592,7 +598,7 @@ __device__ __forceinline__ Hit finish_hit(const SceneView& S, d3 o, d3 d, const 
                 int vdex = (ndir + 2) % 3, udex = (ndir + 1) % 3;
                 double v = 0.5 + (comp(h.pos, vdex) - comp(p0, vdex)) / 400.0;
                 double u = 0.5 + (comp(h.pos, udex) - comp(p0, udex)) / 300.0;
-                color_uv(S.tex[ob.texture], S.texels, u, v, h.color);
+                color_uv(tex_of(ob), S.texels, u, v, h.color);
             }
         } else if (ob.type == OBJ_SPHERE) {
             d3 c = ld3(ob.p0);
@@ -607,7 +613,7 @@ __device__ __forceinline__ Hit finish_hit(const SceneView& S, d3 o, d3 d, const 
                 double phi = acos(t);
                 double u = theta / SPPM_PI, v = phi / (2 * SPPM_PI);
                 v = (dot(N, cross(texU, texV)) < 0) ? (1 - v) : v;
-                color_uv(S.tex[ob.texture], S.texels, u, v, h.color);
+                color_uv(tex_of(ob), S.texels, u, v, h.color);
             }
         } else {
             // normal = Su x Sv at the winning (u, v), turned against the ray (Bezier.h:267-273)
@@ -617,7 +623,7 @@ __device__ __forceinline__ Hit finish_hit(const SceneView& S, d3 o, d3 d, const 
             if (dot(N, d) > 0) N = neg(N);
             h.n = get_unit(N);
             // GetColor(u, t): the second texture coordinate is the ray parameter (Bezier.h:278)
-            if (ob.texture >= 0) color_uv(S.tex[ob.texture], S.texels, (double)nr.u, (double)nr.t, h.color);
+            if (ob.texture >= 0) color_uv(tex_of(ob), S.texels, (double)nr.u, (double)nr.t, h.color);
         }
     }
     return h;

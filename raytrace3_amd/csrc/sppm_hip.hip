@@ -54,7 +54,6 @@ struct NewtonTask { uint32_t park, patch; };
 struct SceneParams {
     const char* blob;
     int blob_bytes, off_box, off_cp, off_pobj, n_objs, n_patches;
-    const TexDesc* tex;
     const uchar4* texels;
     const float* pw_q;      // Newton tables: power-basis coefficients around the patch centre, n_patches x 48
     const double* pw_c;     // and the centres, n_patches x 3
@@ -109,7 +108,6 @@ __device__ __forceinline__ SceneView stage_scene(const SceneParams& sp) {
     S.patch_obj = (const int*)(base + sp.off_pobj);
     S.n_objs = sp.n_objs;
     S.n_patches = sp.n_patches;
-    S.tex = sp.tex;
     S.texels = sp.texels;
     return S;
 }
@@ -1139,7 +1137,7 @@ struct sppm_ctx {
     // scene
     bool have_scene = false;
     DevBuf<char> blob; int blob_bytes = 0, off_box = 0, off_cp = 0, off_pobj = 0, n_objs = 0, n_patches = 0;
-    DevBuf<TexDesc> tex; DevBuf<uchar4> texels;
+    DevBuf<uchar4> texels;
     DevBuf<float> pw_q; DevBuf<double> pw_c;   // Newton tables (power basis around the patch centres)
     DevBuf<DevLight> lights; int n_lights = 0;
     // eye pass
@@ -1200,7 +1198,7 @@ struct sppm_ctx {
     SceneParams scene_params() const {
         SceneParams sp;
         sp.blob = blob.p; sp.blob_bytes = blob_bytes; sp.off_box = off_box; sp.off_cp = off_cp; sp.off_pobj = off_pobj;
-        sp.n_objs = n_objs; sp.n_patches = n_patches; sp.tex = tex.p; sp.texels = texels.p;
+        sp.n_objs = n_objs; sp.n_patches = n_patches; sp.texels = texels.p;
         sp.pw_q = pw_q.p; sp.pw_c = pw_c.p;
         return sp;
     }
@@ -1302,7 +1300,7 @@ void sppm_destroy(sppm_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->pw_q.release(); ctx->pw_c.release();
-    ctx->blob.release(); ctx->tex.release(); ctx->texels.release(); ctx->lights.release();
+    ctx->blob.release(); ctx->texels.release(); ctx->lights.release();
     ctx->raw.release(); ctx->park[0].release(); ctx->park[1].release(); ctx->ntask[0].release(); ctx->ntask[1].release(); ctx->nres.release();
     ctx->bucket_of.release(); ctx->hist.release(); ctx->hstart.release();
     ctx->hp_pos.release(); ctx->hp_nr.release(); ctx->hp_wgt.release(); ctx->hp_tao.release(); ctx->hp_meta.release(); ctx->hp_r2.release();
@@ -1347,6 +1345,15 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
                 if (b[3 + c] < v) b[3 + c] = v;
             }
     }
+    // textures -> packed uchar4
+    std::vector<TexDesc> td((size_t)std::max(1, s->n_textures));
+    size_t total = 0;
+    for (int t = 0; t < s->n_textures; t++) {
+        if (s->textures[t].rows <= 0 || s->textures[t].cols <= 0 || !s->textures[t].texels)
+            return fail(ctx, SPPM_E_INVALID, "empty texture");
+        td[t].rows = s->textures[t].rows; td[t].cols = s->textures[t].cols; td[t].offset = (unsigned)total; td[t].pad = 0;
+        total += (size_t)td[t].rows * td[t].cols;
+    }
     bool dual_lobe = false;
     for (int i = 0; i < no; i++) {
         const sppm_object& so = s->objects[i];
@@ -1368,7 +1375,9 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
         // Material::IsDiff etc.: !IsZero(vec), where IsZero(vec) is true if ANY component is ~0 (Element.h:16-18, Vec3.h:72-79)
         o.flags = (any_zero3(so.material.diff) ? 0 : F_DIFF) | (any_zero3(so.material.refl) ? 0 : F_REFL) |
                   (any_zero3(so.material.refr) ? 0 : F_REFR);
-        o.first_patch = so.first_patch; o.n_patches = so.n_patches; o.pad = 0;
+        o.first_patch = so.first_patch; o.n_patches = so.n_patches;
+        o.tex_rows = o.tex_cols = 0; o.tex_off = 0;
+        if (o.texture >= 0) { o.tex_rows = td[o.texture].rows; o.tex_cols = td[o.texture].cols; o.tex_off = td[o.texture].offset; }
         if ((o.flags & F_REFL) && (o.flags & F_REFR)) dual_lobe = true;
         if (so.type == SPPM_OBJ_BEZIER) {
             if (so.first_patch < 0 || so.n_patches < 0 || so.first_patch + so.n_patches > np)
@@ -1410,23 +1419,12 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
     HIPCHK(ctx->blob.reserve((size_t)bytes));
     HIPCHK(hipMemcpy(ctx->blob.p, blob.data(), (size_t)bytes, hipMemcpyHostToDevice));
     ctx->blob_bytes = bytes; ctx->off_box = off_box; ctx->off_cp = off_cp; ctx->off_pobj = off_pobj; ctx->n_objs = no; ctx->n_patches = np;
-    // textures -> packed uchar4
-    std::vector<TexDesc> td((size_t)std::max(1, s->n_textures));
-    size_t total = 0;
-    for (int t = 0; t < s->n_textures; t++) {
-        if (s->textures[t].rows <= 0 || s->textures[t].cols <= 0 || !s->textures[t].texels)
-            return fail(ctx, SPPM_E_INVALID, "empty texture");
-        td[t].rows = s->textures[t].rows; td[t].cols = s->textures[t].cols; td[t].offset = (unsigned)total; td[t].pad = 0;
-        total += (size_t)td[t].rows * td[t].cols;
-    }
     std::vector<uchar4> tx(std::max<size_t>(1, total));
     for (int t = 0; t < s->n_textures; t++) {
         const uint8_t* src = s->textures[t].texels;
         uchar4* dst = tx.data() + td[t].offset;
         for (size_t k = 0; k < (size_t)td[t].rows * td[t].cols; k++) dst[k] = make_uchar4(src[3 * k], src[3 * k + 1], src[3 * k + 2], 0);
     }
-    HIPCHK(ctx->tex.reserve(td.size()));
-    HIPCHK(hipMemcpy(ctx->tex.p, td.data(), td.size() * sizeof(TexDesc), hipMemcpyHostToDevice));
     HIPCHK(ctx->texels.reserve(tx.size()));
     HIPCHK(hipMemcpy(ctx->texels.p, tx.data(), tx.size() * sizeof(uchar4), hipMemcpyHostToDevice));
     std::vector<DevLight> dl((size_t)s->n_lights);
