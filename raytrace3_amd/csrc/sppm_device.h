@@ -188,12 +188,19 @@ __device__ __forceinline__ TexDesc tex_of(const DevObject& ob) {
 }
 
 // ------------------------------------------------------------------ Element.h:61-72 Texture::colorUV
-__device__ __forceinline__ void color_uv(const TexDesc t, const uchar4* __restrict__ texels, double u, double v, float out[3]) {
+// The lookup in two halves, so that a caller can put independent work between asking for the four texels and
+// blending them: tex_fetch does the index arithmetic and issues the loads, tex_blend the bilinear weights.
+struct TexTap {
+    uchar4 a, b, c, d;      // texels (r1,c1) (r1,c2) (r2,c1) (r2,c2)
+    double detR, detC;
+    int on;                 // 0: no texture on this hit, the object's own colour stands
+};
+__device__ __forceinline__ void tex_fetch(const TexDesc t, const uchar4* __restrict__ texels, double u, double v, TexTap& tap) {
     int rows = t.rows, cols = t.cols;
     double row = (u - floor(u)) * rows, col = (v - floor(v)) * cols;
     int r1 = (int)floor(row + 1e-10), r2 = r1 + 1;
     int c1 = (int)floor(col + 1e-10), c2 = c1 + 1;
-    double detR = r2 - row, detC = c2 - col;
+    tap.detR = r2 - row; tap.detC = c2 - col;
     r1 = (r1 >= 0) ? (r1 >= rows ? 0 : r1) : (rows - 1);
     c1 = (c1 >= 0) ? (c1 >= cols ? 0 : c1) : (cols - 1);
     r2 = (r2 < rows) ? r2 : 0;
@@ -201,13 +208,22 @@ __device__ __forceinline__ void color_uv(const TexDesc t, const uchar4* __restri
     r2 = r2 < 0 ? 0 : r2;  // memory-safety guard for NaN coordinates (the reference would index out of bounds)
     c2 = c2 < 0 ? 0 : c2;
     const uchar4* base = texels + t.offset;
-    uchar4 a = base[(size_t)r1 * cols + c1], b = base[(size_t)r1 * cols + c2];
-    uchar4 c = base[(size_t)r2 * cols + c1], d = base[(size_t)r2 * cols + c2];
+    tap.a = base[(size_t)r1 * cols + c1]; tap.b = base[(size_t)r1 * cols + c2];
+    tap.c = base[(size_t)r2 * cols + c1]; tap.d = base[(size_t)r2 * cols + c2];
+    tap.on = 1;
+}
+__device__ __forceinline__ void tex_blend(const TexTap& tap, float out[3]) {
+    const double detR = tap.detR, detC = tap.detC;
     double wa = detR * detC, wb = detR * (1 - detC), wc = (1 - detR) * detC, wd = (1 - detR) * (1 - detC);
     const double k = 1.0 / 255.0;
-    out[0] = (float)((a.x * wa + b.x * wb + c.x * wc + d.x * wd) * k);
-    out[1] = (float)((a.y * wa + b.y * wb + c.y * wc + d.y * wd) * k);
-    out[2] = (float)((a.z * wa + b.z * wb + c.z * wc + d.z * wd) * k);
+    out[0] = (float)((tap.a.x * wa + tap.b.x * wb + tap.c.x * wc + tap.d.x * wd) * k);
+    out[1] = (float)((tap.a.y * wa + tap.b.y * wb + tap.c.y * wc + tap.d.y * wd) * k);
+    out[2] = (float)((tap.a.z * wa + tap.b.z * wb + tap.c.z * wc + tap.d.z * wd) * k);
+}
+__device__ __forceinline__ void color_uv(const TexDesc t, const uchar4* __restrict__ texels, double u, double v, float out[3]) {
+    TexTap tap;
+    tex_fetch(t, texels, u, v, tap);
+    tex_blend(tap, out);
 }
 
 // ------------------------------------------------------------------ Bezier.h:20-51 AABBbox::intersect
@@ -569,11 +585,18 @@ __device__ __forceinline__ void bezier_patch_masks(const SceneView& S, bool acti
 
 struct Hit {
     d3 pos, n;
-    float color[3];
+    float color[3];   // the object's colour; superseded by the texture where tap.on (hit_color gives the final one)
+    TexTap tap;       // texture lookup in flight
     double dist;
     int obj;      // -1 = none
     int inside;
 };
+// GetColor of the hit: the blended texels if the object is textured, its plain colour otherwise.  Called as late as
+// the caller can afford: the texel loads issued by finish_hit travel meanwhile.
+__device__ __forceinline__ void hit_color(const Hit& h, float out[3]) {
+    out[0] = h.color[0]; out[1] = h.color[1]; out[2] = h.color[2];
+    if (h.tap.on) tex_blend(h.tap, out);
+}
 
 // Collision of the winner only (GetColor is a pure function, so evaluating it for the nearest
 // object alone gives what the reference's per-object evaluation gives).
@@ -581,6 +604,8 @@ __device__ __forceinline__ Hit finish_hit(const SceneView& S, d3 o, d3 d, const 
     Hit h;
     h.obj = nr.obj; h.dist = nr.dist; h.inside = nr.inside;
     h.pos = mk(0, 0, 0); h.n = mk(0, 0, 0); h.color[0] = h.color[1] = h.color[2] = 0;
+    h.tap.on = 0; h.tap.detR = h.tap.detC = 0;
+    h.tap.a = h.tap.b = h.tap.c = h.tap.d = make_uchar4(0, 0, 0, 0);
     if (nr.obj >= 0) {
         const DevObject& ob = S.objs[nr.obj];
         h.pos = o + d * nr.dist;
@@ -598,7 +623,7 @@ __device__ __forceinline__ Hit finish_hit(const SceneView& S, d3 o, d3 d, const 
                 int vdex = (ndir + 2) % 3, udex = (ndir + 1) % 3;
                 double v = 0.5 + (comp(h.pos, vdex) - comp(p0, vdex)) / 400.0;
                 double u = 0.5 + (comp(h.pos, udex) - comp(p0, udex)) / 300.0;
-                color_uv(tex_of(ob), S.texels, u, v, h.color);
+                tex_fetch(tex_of(ob), S.texels, u, v, h.tap);
             }
         } else if (ob.type == OBJ_SPHERE) {
             d3 c = ld3(ob.p0);
@@ -613,7 +638,7 @@ __device__ __forceinline__ Hit finish_hit(const SceneView& S, d3 o, d3 d, const 
                 double phi = acos(t);
                 double u = theta / SPPM_PI, v = phi / (2 * SPPM_PI);
                 v = (dot(N, cross(texU, texV)) < 0) ? (1 - v) : v;
-                color_uv(tex_of(ob), S.texels, u, v, h.color);
+                tex_fetch(tex_of(ob), S.texels, u, v, h.tap);
             }
         } else {
             // normal = Su x Sv at the winning (u, v), turned against the ray (Bezier.h:267-273)
@@ -623,7 +648,7 @@ __device__ __forceinline__ Hit finish_hit(const SceneView& S, d3 o, d3 d, const 
             if (dot(N, d) > 0) N = neg(N);
             h.n = get_unit(N);
             // GetColor(u, t): the second texture coordinate is the ray parameter (Bezier.h:278)
-            if (ob.texture >= 0) color_uv(tex_of(ob), S.texels, (double)nr.u, (double)nr.t, h.color);
+            if (ob.texture >= 0) tex_fetch(tex_of(ob), S.texels, (double)nr.u, (double)nr.t, h.tap);
         }
     }
     return h;

@@ -432,7 +432,16 @@ __global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneP
             if (active) {
                 dep++;
                 const DevObject& ob = S.objs[hit.obj];
-                const float bw[3] = {hit.color[0] * carry[0], hit.color[1] * carry[1], hit.color[2] * carry[2]};
+                const bool has_refl = ob.flags & F_REFL, has_refr = ob.flags & F_REFR;
+                d3 refl_d = mk(0, 0, 0), refr_d = mk(0, 0, 0);
+                if (has_refl) refl_d = get_unit(get_refl(d, hit.n));                      // Raytracer.h:320-326
+                if (has_refr) {                                                           // Raytracer.h:327-336
+                    const double refrn = hit.inside ? ob.refrn : 1 / ob.refrn;
+                    refr_d = get_unit(refracted(d, hit.inside ? neg(hit.n) : hit.n, refrn));
+                }
+                float hc[3];
+                hit_color(hit, hc);                                                       // the texels were asked for in finish_hit
+                const float bw[3] = {hc[0] * carry[0], hc[1] * carry[1], hc[2] * carry[2]};
                 if (ob.flags & F_DIFF) {                                                  // Raytracer.h:312-319
                     emit_hp = true;
                     rh.pos[0] = hit.pos.x; rh.pos[1] = hit.pos.y; rh.pos[2] = hit.pos.z;
@@ -440,13 +449,6 @@ __global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneP
                     rh.v[0] = (float)d.x; rh.v[1] = (float)d.y; rh.v[2] = (float)d.z;
                     rh.wgt[0] = bw[0] * ob.diff[0]; rh.wgt[1] = bw[1] * ob.diff[1]; rh.wgt[2] = bw[2] * ob.diff[2];
                     rh.pix = (int)id; rh.node = node; rh.obj = hit.obj;
-                }
-                const bool has_refl = ob.flags & F_REFL, has_refr = ob.flags & F_REFR;
-                d3 refl_d = mk(0, 0, 0), refr_d = mk(0, 0, 0);
-                if (has_refl) refl_d = get_unit(get_refl(d, hit.n));                      // Raytracer.h:320-326
-                if (has_refr) {                                                           // Raytracer.h:327-336
-                    const double refrn = hit.inside ? ob.refrn : 1 / ob.refrn;
-                    refr_d = get_unit(refracted(d, hit.inside ? neg(hit.n) : hit.n, refrn));
                 }
                 if (dep > SPPM_MAX_DEP) {
                     active = false;  // the next NearCollide result would be discarded (Raytracer.h:303-309)
@@ -514,7 +516,9 @@ __global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneP
                     const double refrn = hit.inside ? ob.refrn : 1 / ob.refrn;
                     nd = get_unit(refracted(d, hit.inside ? neg(hit.n) : hit.n, refrn));
                 }
-                carry[0] *= hit.color[0]; carry[1] *= hit.color[1]; carry[2] *= hit.color[2];
+                float hc[3];
+                hit_color(hit, hc);                                                       // the texels were asked for in finish_hit
+                carry[0] *= hc[0]; carry[1] *= hc[1]; carry[2] *= hc[2];
                 o = hit.pos; d = nd;
                 if (dep > SPPM_MAX_DEP) active = false;                                   // Raytracer.h:126-133
             }
@@ -1065,7 +1069,9 @@ __global__ void __launch_bounds__(256) k_debug_near_collide(SceneParams sp, uint
         sppm_collision c;
         c.pos[0] = h.pos.x; c.pos[1] = h.pos.y; c.pos[2] = h.pos.z;
         c.n[0] = h.n.x; c.n[1] = h.n.y; c.n[2] = h.n.z;
-        c.color[0] = h.color[0]; c.color[1] = h.color[1]; c.color[2] = h.color[2];
+        float hc[3];
+        hit_color(h, hc);
+        c.color[0] = hc[0]; c.color[1] = hc[1]; c.color[2] = hc[2];
         c.dist = h.obj >= 0 ? h.dist : 0.0;
         c.obj = h.obj; c.inside = h.inside;
         out[i] = c;
