@@ -1191,6 +1191,7 @@ struct sppm_ctx {
     bool accumulate_stats = false;        // counters and timing spans run on over eye passes (sppm_stats_mode)
     bool check_pending = false;           // launches since the last look at the overflow flags
     DevBuf<float> pic;
+    float* host_pic = nullptr; size_t host_pic_n = 0;   // pinned staging area of sppm_resolve
     uint64_t last_rounds = 0, last_per_round = 0;
     uint64_t batch = 1u << 22;            // photons traced, sorted and gathered together (128 B of deposit buffers per photon x 14)
     // HIP-event spans on the stream, read back (and only then waited for) by sppm_get_timings
@@ -1312,6 +1313,7 @@ void sppm_destroy(sppm_ctx* ctx) {
     ctx->hp_pos.release(); ctx->hp_nr.release(); ctx->hp_wgt.release(); ctx->hp_tao.release(); ctx->hp_meta.release(); ctx->hp_r2.release();
     ctx->dep.release(); ctx->sdep.release(); ctx->pieces.release();
     ctx->dstart.release(); ctx->scan_partial.release(); ctx->ctl.release(); ctx->counters.release(); ctx->pic.release();
+    if (ctx->host_pic) (void)hipHostFree(ctx->host_pic);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -1845,8 +1847,14 @@ int sppm_resolve(sppm_ctx* ctx, double* pic, int accumulate) {
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(ctx->pic.reserve(n));
     if (int rc = sppm_resolve_device(ctx, ctx->pic.p)) return rc;
-    std::vector<float> h(n);
-    HIPCHK(hipMemcpyAsync(h.data(), ctx->pic.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->host_pic_n < n) {
+        if (ctx->host_pic) (void)hipHostFree(ctx->host_pic);
+        ctx->host_pic = nullptr; ctx->host_pic_n = 0;
+        HIPCHK(hipHostMalloc((void**)&ctx->host_pic, n * sizeof(float), hipHostMallocDefault));
+        ctx->host_pic_n = n;
+    }
+    const float* h = ctx->host_pic;
+    HIPCHK(hipMemcpyAsync(ctx->host_pic, ctx->pic.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (int rc = check_deferred(ctx)) return rc;
     if (accumulate) for (size_t i = 0; i < n; i++) pic[i] += (double)h[i];
