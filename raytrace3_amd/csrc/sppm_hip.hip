@@ -170,6 +170,9 @@ __device__ __forceinline__ unsigned long long chunk_alloc(bool want, unsigned lo
     return slot;
 }
 
+#ifndef TRACE_EYE_OCC
+#define TRACE_EYE_OCC 2
+#endif
 #ifndef TRACE_COOP_OCC
 #define TRACE_COOP_OCC 2
 #endif
@@ -230,7 +233,7 @@ struct TraceParams {
 // k_newton solves all tasks of the round at full occupancy, and the next launch resumes the ray
 // from its record.  This keeps the 50 x 10 Newton iterations out of the divergent path loop.
 template <int MODE, bool COOP>
-__global__ void __launch_bounds__(256, COOP ? TRACE_COOP_OCC : 3) k_trace(SceneParams sp, TraceParams tp) {
+__global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC : TRACE_COOP_OCC) : 3) k_trace(SceneParams sp, TraceParams tp) {
     const unsigned long long n_resume = tp.resume ? min(*tp.n_resume_dev, tp.park_cap) : 0ull;   // records beyond the capacity were never written
     const unsigned long long total = n_resume + tp.fresh_count;
     // the host sizes a resume launch without knowing its count: workgroups beyond the work leave at once
@@ -1557,7 +1560,7 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
     const int max_blocks = trace_max_blocks(ctx);
     // persistent workgroups: as many as stay resident (2 per CU with in-wave solves, 3 without), not more
     auto blocks_for = [&](uint64_t items, bool coop) {
-        const int per_cu = ctx->trace_blocks_per_cu > 0 ? ctx->trace_blocks_per_cu : (coop ? 2 : 3);
+        const int per_cu = ctx->trace_blocks_per_cu > 0 ? ctx->trace_blocks_per_cu : (coop ? (mode == MODE_EYE ? TRACE_EYE_OCC : TRACE_COOP_OCC) : 3);
         const uint64_t cap = std::min<uint64_t>((uint64_t)max_blocks, (uint64_t)ctx->num_cu * per_cu);
         return (int)std::max<uint64_t>(1, std::min<uint64_t>(cap, (items + 255) / 256));
     };
