@@ -506,6 +506,11 @@ __device__ __forceinline__ void analytic_nearest(const SceneView& S, bool active
     if (active) near_consider(nr, 10.0 + d.x, d.y > 0 ? 3 : 0, 0, -1, 0, 0, 0);
     return;
 #endif
+    // Objects are visited in index order and a hit replaces the record only when strictly nearer, which is the
+    // (dist, object index) rule of near_consider without its tie test; the Bezier fields of the record stay as
+    // near_init left them, so three values are carried through the loop instead of eight.
+    double best = nr.dist;
+    int bobj = nr.obj, binside = nr.inside;
     for (int a = 0; a < S.n_objs; a++) {
         const DevObject& ob = S.objs[a];
         const int type = __builtin_amdgcn_readfirstlane(ob.type);   // wave-uniform: keep the branch scalar
@@ -514,7 +519,7 @@ __device__ __forceinline__ void analytic_nearest(const SceneView& S, bool active
             double project = dot(d, n);
             if (active && !is_zero(project)) {
                 double dist = dot(ld3(ob.p0) - o, n) / project;
-                if (dist > SPPM_EPS) near_consider(nr, dist, a, 0, -1, 0, 0, 0);
+                if (dist > SPPM_EPS && dist < best) { best = dist; bobj = a; binside = 0; }
             }
         } else if (type == OBJ_SPHERE) {
             d3 L = ld3(ob.p0) - o;
@@ -523,10 +528,14 @@ __device__ __forceinline__ void analytic_nearest(const SceneView& S, bool active
             if (active && !(det2 < SPPM_EPS)) {
                 double det = sqrt(det2);
                 double dist1 = project - det, dist2 = project + det;
-                if (!(dist2 < SPPM_EPS)) near_consider(nr, (dist1 > SPPM_EPS) ? dist1 : dist2, a, (dist1 < SPPM_EPS) ? 1 : 0, -1, 0, 0, 0);
+                if (!(dist2 < SPPM_EPS)) {
+                    const double dist = (dist1 > SPPM_EPS) ? dist1 : dist2;
+                    if (dist < best) { best = dist; bobj = a; binside = (dist1 < SPPM_EPS) ? 1 : 0; }
+                }
             }
         }
     }
+    if (bobj != nr.obj || best != nr.dist) { nr.dist = best; nr.obj = bobj; nr.inside = binside; nr.patch = -1; nr.t = 0; nr.u = 0; nr.v = 0; }
 }
 
 // Bezier objects, solved inside the calling wave (Bezier.h:240-282).
