@@ -511,20 +511,31 @@ __device__ __forceinline__ void analytic_nearest(const SceneView& S, bool active
     // near_init left them, so three values are carried through the loop instead of eight.
     double best = nr.dist;
     int bobj = nr.obj, binside = nr.inside;
-    for (int a = 0; a < S.n_objs; a++) {
-        const DevObject& ob = S.objs[a];
-        const int type = __builtin_amdgcn_readfirstlane(ob.type);   // wave-uniform: keep the branch scalar
+    // The object records sit in LDS; the next object's fields are asked for before the current one is worked on,
+    // so that with two or three waves per SIMD the LDS latency is not paid once per object.
+    const int n_objs = S.n_objs;
+    d3 q_p0 = mk(0, 0, 0), q_n = mk(0, 0, 0);
+    double q_r = 0;
+    int q_type = -1;
+    if (n_objs > 0) { q_p0 = ld3(S.objs[0].p0); q_n = ld3(S.objs[0].n); q_r = S.objs[0].radius; q_type = S.objs[0].type; }
+    for (int a = 0; a < n_objs; a++) {
+        const d3 p0 = q_p0, n = q_n;
+        const double radius = q_r;
+        const int type = __builtin_amdgcn_readfirstlane(q_type);   // wave-uniform: keep the branch scalar
+        if (a + 1 < n_objs) {
+            const DevObject& nx = S.objs[a + 1];
+            q_p0 = ld3(nx.p0); q_n = ld3(nx.n); q_r = nx.radius; q_type = nx.type;
+        }
         if (type == OBJ_PLANE) {
-            d3 n = ld3(ob.n);
             double project = dot(d, n);
             if (active && !is_zero(project)) {
-                double dist = dot(ld3(ob.p0) - o, n) / project;
+                double dist = dot(p0 - o, n) / project;
                 if (dist > SPPM_EPS && dist < best) { best = dist; bobj = a; binside = 0; }
             }
         } else if (type == OBJ_SPHERE) {
-            d3 L = ld3(ob.p0) - o;
+            d3 L = p0 - o;
             double project = dot(L, d);
-            double det2 = ob.radius * ob.radius - (dot(L, L) - project * project);
+            double det2 = radius * radius - (dot(L, L) - project * project);
             if (active && !(det2 < SPPM_EPS)) {
                 double det = sqrt(det2);
                 double dist1 = project - det, dist2 = project + det;
