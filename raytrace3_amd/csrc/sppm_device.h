@@ -255,20 +255,22 @@ __device__ __forceinline__ bool aabb_hit(const double* __restrict__ box, d3 o, d
 // convex hull of the control points, hence in the patch box: its t is >= this bound for margin > 0.01.
 // A patch whose bound exceeds a hit already found can therefore be skipped without changing the result of
 // Bezier3Obj::GetIntersect / Scene::NearCollide (both keep the nearest hit).
-#define SPPM_PRUNE_MARGIN 0.011
-#define SPPM_PRUNE_SLACK 1e-3f
+// The bound only orders and prunes, it decides no hit: it is computed in fp32 (coordinates and ray parameters of a
+// few hundred units: errors below 1e-4), and the slack of the comparison absorbs that.
+#define SPPM_PRUNE_MARGIN 0.011f
+#define SPPM_PRUNE_SLACK 2e-3f
 __device__ __forceinline__ float aabb_entry_lb(const double* __restrict__ box, d3 o, d3 d) {
-    double t0 = 0.0;
+    float t0 = 0.0f;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        const double di = comp(d, i);
-        if (fabs(di) > 1e-12) {
-            const double inv = 1.0 / di;
-            const double a = (box[i] - SPPM_PRUNE_MARGIN - comp(o, i)) * inv, b = (box[3 + i] + SPPM_PRUNE_MARGIN - comp(o, i)) * inv;
-            t0 = fmax(t0, fmin(a, b));
+        const float di = (float)comp(d, i);
+        if (fabsf(di) > 1e-12f) {
+            const float inv = __frcp_rn(di);
+            const float lo = (float)(box[i] - comp(o, i)) - SPPM_PRUNE_MARGIN, hi = (float)(box[3 + i] - comp(o, i)) + SPPM_PRUNE_MARGIN;
+            t0 = fmaxf(t0, fminf(lo * inv, hi * inv));
         }
     }
-    return (float)t0;
+    return t0;
 }
 
 // ------------------------------------------------------------------ bicubic Bernstein evaluation (Bezier.h:69-111), fp32
