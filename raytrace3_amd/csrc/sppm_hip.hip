@@ -793,7 +793,10 @@ __device__ __forceinline__ float wave_total_f(float v) {
 #ifndef GATHER_SPLIT_ROWS
 #define GATHER_SPLIT_ROWS 24u
 #endif
-static_assert(GATHER_SPLIT_ROWS % GATHER_ROWS == 0, "a sweep is cut between passes of GATHER_ROWS rows");
+#ifndef GATHER_OWN_ROWS
+#define GATHER_OWN_ROWS 24u     // rows the owner of a cell sweeps itself before it queues the rest
+#endif
+static_assert(GATHER_SPLIT_ROWS % GATHER_ROWS == 0 && GATHER_OWN_ROWS % GATHER_ROWS == 0, "a sweep is cut between passes of GATHER_ROWS rows");
 struct GatherPiece { uint32_t tile_base, lead, row_begin, row_end; };   // lead: lane of one HitPoint of the cell in its tile
 
 template <bool PIECE>
@@ -835,7 +838,7 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
         uint32_t F = 0;                     // flat offset of the next row
         uint32_t cur_end = 0, cur_base = 0; // current range: flat end, (deposit index - flat index)
         uint32_t cur_klo = 0, cur_khi = 0;  // its cell key
-        uint32_t F_limit = GATHER_SPLIT_ROWS * 64u;   // this sweep stops here
+        uint32_t F_limit = GATHER_OWN_ROWS * 64u;   // this sweep stops here
         if (PIECE) {
             F = piece.row_begin * 64u; F_limit = piece.row_end * 64u;
             while (cur_end <= F && cells) {           // walk to the range that holds the first entry wanted
@@ -932,7 +935,7 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
                 for (uint32_t i = lane; i < n_p; i += 64) {
                     GatherPiece pc;
                     pc.tile_base = base; pc.lead = (uint32_t)lead;
-                    pc.row_begin = (i + 1u) * GATHER_SPLIT_ROWS; pc.row_end = (i + 2u) * GATHER_SPLIT_ROWS;
+                    pc.row_begin = GATHER_OWN_ROWS + i * GATHER_SPLIT_ROWS; pc.row_end = pc.row_begin + GATHER_SPLIT_ROWS;
                     pieces[first + i] = pc;
                 }
             } else {
