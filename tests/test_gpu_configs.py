@@ -335,3 +335,27 @@ def test_radius_update_knob_against_oracle(gpu):
     gpu.photon_pass(20, 100, SEED)
     hp = gpu.hitpoints()
     assert not hp["N"].any() and np.all(hp["R2"] == 2.0) and hp["newN"].sum() == gpu.counters()["accepted"]
+
+
+def test_image_statistics_match_the_references_own_random_stream(gpu):
+    """The GPU draws from counter-based streams, the reference from one global cv::RNG stream (the oracle's
+    literal mode: same MWC recurrence and draw order, fp64).  Pixel by pixel the two are different samples of the
+    same estimator; over blocks of pixels their means agree."""
+    scene, cam = scenes.scene_spheres_plane(True), scenes.default_camera(48, 36)
+    gpu.set_scene(scene)
+    gpu.eye_pass(cam, SEED)
+    gpu.photon_pass(1500, 100, SEED)
+    g = gpu.resolve()
+    lit = ol.OracleContext(rng_literal=True)
+    lit.set_scene(scene)
+    lit.eye_pass(cam, SEED)
+    lit.photon_pass(1500, 100, SEED, mode=ol.GATHER_KDTREE)
+    c = lit.resolve()
+    assert abs(g.sum() / c.sum() - 1) < 0.02
+    for ch in range(3):
+        assert abs(g[..., ch].sum() / c[..., ch].sum() - 1) < 0.03
+    gb = g.reshape(6, 6, 8, 6, 3).mean(axis=(1, 3))      # 6 x 8 blocks of 6 x 6 pixels
+    cb = c.reshape(6, 6, 8, 6, 3).mean(axis=(1, 3))
+    lit_blocks = cb > 0.2 * cb.mean()
+    assert np.corrcoef(gb.ravel(), cb.ravel())[0, 1] > 0.99
+    assert np.abs(gb[lit_blocks] / cb[lit_blocks] - 1).mean() < 0.06

@@ -70,6 +70,50 @@ def test_near_collide_analytic_scene(gpu):
     assert np.allclose(g["color"][hit], c["color"][hit], rtol=0, atol=1e-6)
 
 
+def test_near_collide_random_analytic_scenes(gpu):
+    """Scene::NearCollide over randomly placed planes and spheres (overlapping spheres, planes through the cloud of
+    ray origins, origins inside spheres, rays grazing and parallel to planes, equal objects listed twice so that the
+    first-wins tie rule of Scene.h:171-178 is exercised): object index, inside flag, distance and normal equal the
+    oracle's for every ray."""
+    rng = np.random.default_rng(2024)
+    total_hits = 0
+    for trial in range(8):
+        s = scenes.FlatScene()
+        mats = (scenes.WHITE_DIFF, scenes.MIRROR, scenes.REFR0, scenes.MIRROR2)
+        n_planes, n_spheres = int(rng.integers(1, 5)), int(rng.integers(1, 8))
+        for k in range(n_planes):
+            n = rng.normal(size=3)
+            if k == 0 or rng.random() < 0.5:             # axis-aligned, as every plane of the reference's scenes (and the
+                                                         # first one always: its copy below must be the same plane bit for bit)
+                n = np.eye(3)[rng.integers(0, 3)] * rng.choice([-1.0, 1.0])
+            s.add_plane(rng.normal(size=3) * 40, n, rng.random(3), mats[rng.integers(0, 4)])
+        for _ in range(n_spheres):
+            s.add_sphere(float(rng.uniform(2, 30)), rng.normal(size=3) * 30, rng.random(3), mats[rng.integers(0, 4)])
+        # the last sphere and the first plane once more: equal distances, the lower index must win
+        last, first = s.objects[-1], s.objects[0]
+        s.add_sphere(last["radius"], last["p0"], (0.1, 0.2, 0.3), scenes.WHITE_DIFF)
+        s.add_plane(first["p0"], first["n"], (0.3, 0.2, 0.1), scenes.MIRROR)
+        s.add_light((0, 50, 0), (1000, 1000, 1000))
+        gpu.set_scene(s)
+        o = _oracle(s)
+        n_rays = 4096
+        org = rng.normal(size=(n_rays, 3)) * 25
+        d = rng.normal(size=(n_rays, 3))
+        d[: n_rays // 8] *= np.array([1.0, 1.0, 0.0])    # rays parallel to the z planes
+        d[n_rays // 8: n_rays // 4, 0] *= 1e-5           # nearly parallel to the x planes (|project| around the 1e-4 guard)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        g, c = gpu.near_collide(org, d, SEED), o.near_collide(org, d, SEED)
+        assert np.array_equal(g["obj"], c["obj"]), trial
+        assert np.array_equal(g["inside"], c["inside"]), trial
+        hit = c["obj"] >= 0
+        total_hits += int(hit.sum())
+        assert np.allclose(g["dist"][hit], c["dist"][hit], rtol=1e-12, atol=1e-9)
+        assert np.allclose(g["n"][hit], c["n"][hit], rtol=0, atol=1e-12)
+        assert np.allclose(g["color"][hit], c["color"][hit], rtol=0, atol=1e-6)
+        assert not np.isin(c["obj"], [len(s.objects) - 1, len(s.objects) - 2]).any()     # the duplicates never win
+    assert total_hits > 20000
+
+
 def test_textured_objects(gpu):
     scene = scenes.scene_teapot(1, textured=True)
     gpu.set_scene(scene)
