@@ -359,3 +359,34 @@ def test_image_statistics_match_the_references_own_random_stream(gpu):
     lit_blocks = cb > 0.2 * cb.mean()
     assert np.corrcoef(gb.ravel(), cb.ravel())[0, 1] > 0.99
     assert np.abs(gb[lit_blocks] / cb[lit_blocks] - 1).mean() < 0.06
+
+
+def test_parked_newton_path_gives_the_same_pass(gpu):
+    """The alternative to the in-wave Bezier solves (SPPM_EYE_SCATTER=0, SPPM_PHOTON_COOP=0): rays that meet
+    patch boxes are parked, k_newton solves them, a resume launch merges the results.  Same HitPoints, same
+    counters but the number of Newton solves (the pruning sees the patches in another order), same image."""
+    scene, cam = scenes.scene_teapot(1), scenes.default_camera(160, 120)
+    gpu.set_scene(scene)
+    gpu.eye_pass(cam, SEED)
+    gpu.photon_pass(300, 100, SEED)
+    os.environ["SPPM_EYE_SCATTER"] = "0"
+    os.environ["SPPM_PHOTON_COOP"] = "0"
+    try:
+        parked = SppmContext(0)
+    finally:
+        del os.environ["SPPM_EYE_SCATTER"], os.environ["SPPM_PHOTON_COOP"]
+    parked.set_scene(scene)
+    parked.eye_pass(cam, SEED)
+    parked.photon_pass(300, 100, SEED)
+    a, b = gpu.hitpoints(), parked.hitpoints()
+    a, b = a[np.argsort(_key(a))], b[np.argsort(_key(b))]
+    assert np.array_equal(_key(a), _key(b))
+    assert np.allclose(a["pos"], b["pos"], rtol=0, atol=1e-9) and np.array_equal(a["obj"], b["obj"])
+    ca, cb = gpu.counters(), parked.counters()
+    for k in ("photons", "segments", "deposits", "hitpoints", "eye_segments"):
+        assert ca[k] == cb[k], k
+    assert abs(ca["accepted"] - cb["accepted"]) <= 1e-4 * ca["accepted"]
+    assert np.array_equal(a["newN"], b["newN"]) or (a["newN"] != b["newN"]).mean() < 1e-3
+    pa, pb = gpu.resolve(), parked.resolve()
+    assert np.allclose(pa, pb, rtol=1e-3, atol=1e-5 * pa.mean())
+    parked.close()
