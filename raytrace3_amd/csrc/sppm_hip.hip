@@ -221,6 +221,13 @@ struct TraceParams {
     const uint8_t* occ;                       // one byte per bucket: some HitPoint lies within one cell of a cell of that bucket
                                               // (null: every deposit is kept)
     unsigned long long* wave_chunks;          // per wave slot {next, end} of its open deposit-slot chunk
+    // Direct placement (null: off).  place[b] .. place[b + 1] is the room the sorted deposit array holds for bucket b,
+    // laid out from the histogram of an earlier batch of the same size; a deposit goes straight to
+    // sorted[place[b] + (its rank among the deposits of b)], the rank being the value the histogram atomic returns,
+    // and the counting sort is not needed.  A deposit that finds its bucket full goes to the list `over`.
+    const uint32_t* place;
+    Deposit* sorted;
+    Deposit* over; unsigned long long* n_over; unsigned long long over_cap;
 };
 
 // One kernel for both passes, on persistent wavefronts: a lane that finishes (or parks) its
@@ -527,13 +534,29 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
             }
             if (dp) ndep++;
             dp = dp && keep;
-            const unsigned long long slot = chunk_alloc(dp, slot_next, slot_end, tp.n_dep, TRACE_SLOT_CHUNK);
-            if (dp) {
-                if (slot < tp.dep_cap) {
+            if (tp.place) {
+                if (dp) {
+                    const uint32_t bk = db.bucket & 0xffffffu;
+                    const uint32_t base = tp.place[bk], room = tp.place[bk + 1] - base;
+                    const uint32_t rank = atomicAdd(&tp.dcount[bk], 1u);
                     Deposit rec; rec.a = da; rec.b = db;
-                    tp.dep[slot] = rec;
-                    atomicAdd(&tp.dcount[db.bucket & 0xffffffu], 1u);
-                } else atomicOr(&tp.counters->overflow, 4u);
+                    if (rank < room) {
+                        tp.sorted[base + rank] = rec;
+                    } else {
+                        const unsigned long long s = atomicAdd(tp.n_over, 1ull);
+                        if (s < tp.over_cap) tp.over[s] = rec;
+                        else atomicOr(&tp.counters->overflow, 4u);
+                    }
+                }
+            } else {
+                const unsigned long long slot = chunk_alloc(dp, slot_next, slot_end, tp.n_dep, TRACE_SLOT_CHUNK);
+                if (dp) {
+                    if (slot < tp.dep_cap) {
+                        Deposit rec; rec.a = da; rec.b = db;
+                        tp.dep[slot] = rec;
+                        atomicAdd(&tp.dcount[db.bucket & 0xffffffu], 1u);
+                    } else atomicOr(&tp.counters->overflow, 4u);
+                }
             }
         }
         STAMP(5);
@@ -803,7 +826,8 @@ template <bool PIECE>
 __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
                                             const double* __restrict__ hp_r2,
                                             const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, const uint32_t n_hp,
-                                            const uint32_t* __restrict__ dstart, const Deposit* __restrict__ deps,
+                                            const uint32_t* __restrict__ dstart, const uint32_t* __restrict__ dlen,
+                                            const Deposit* __restrict__ deps,
                                             const GridParams g, GatherPiece* __restrict__ pieces, unsigned long long* n_pieces,
                                             const uint32_t piece_cap, unsigned int* overflow, const GatherPiece piece,
                                             uint32_t& cand, uint32_t& acc_n) {
@@ -831,6 +855,7 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
             const uint32_t b = key_bucket(nb_key, g.mask);
             nb_s = dstart[b];
             nb_len = dstart[b + 1] - nb_s;
+            if (dlen) nb_len = min(nb_len, dlen[b]);   // directly placed deposits: the bucket's room is only partly filled
         }
         // The non-empty ranges, concatenated, form one flat list; a row is 64 consecutive entries of it
         // (lane l of the row at flat offset F holds entry F + l), so rows are full except the last.
@@ -963,7 +988,8 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
 // other eighths when its own is drained (tile cost varies with the photon density around it).
 __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
                                                 const double* __restrict__ hp_r2, const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
-                                                const uint32_t* __restrict__ dstart, const Deposit* __restrict__ deps,
+                                                const uint32_t* __restrict__ dstart, const uint32_t* __restrict__ dlen,
+                                                const Deposit* __restrict__ deps,
                                                 GridParams g, uint32_t* tile_ctr, GatherPiece* __restrict__ pieces,
                                                 unsigned long long* n_pieces, uint32_t piece_cap, DevCounters* counters) {
     const uint32_t n_tiles = (n_hp + GATHER_TILE - 1u) / GATHER_TILE;
@@ -977,7 +1003,7 @@ __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_po
             if (lane_id() == 0) t = atomicAdd(&tile_ctr[q * 16], 1u);
             t = bcast_u(t, 0) + q * per;
             if (t >= q_end) break;
-            gather_tile<false>(t * GATHER_TILE, hp_pos, hp_nr, hp_r2, hp_wgt, hp_tao, n_hp, dstart, deps, g, pieces, n_pieces, piece_cap,
+            gather_tile<false>(t * GATHER_TILE, hp_pos, hp_nr, hp_r2, hp_wgt, hp_tao, n_hp, dstart, dlen, deps, g, pieces, n_pieces, piece_cap,
                                &counters->overflow, GatherPiece{0, 0, 0, 0}, cand, acc_n);
         }
     }
@@ -990,7 +1016,8 @@ __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_po
 // The queued pieces of heavy cells (see GATHER_SPLIT_ROWS), one wave per piece at a time.
 __global__ void __launch_bounds__(256) k_gather_split(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
                                                       const double* __restrict__ hp_r2, const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
-                                                      const uint32_t* __restrict__ dstart, const Deposit* __restrict__ deps, GridParams g,
+                                                      const uint32_t* __restrict__ dstart, const uint32_t* __restrict__ dlen,
+                                                      const Deposit* __restrict__ deps, GridParams g,
                                                       const GatherPiece* __restrict__ pieces, const unsigned long long* __restrict__ n_pieces,
                                                       uint32_t piece_cap, unsigned long long* next_piece, DevCounters* counters) {
     const unsigned long long n = min(*n_pieces, (unsigned long long)piece_cap);
@@ -1000,7 +1027,7 @@ __global__ void __launch_bounds__(256) k_gather_split(const PosKey* __restrict__
     // play (a launch with nothing queued costs no atomic at all)
     for (unsigned long long i = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n;) {
         const GatherPiece pc = pieces[i];
-        gather_tile<true>(pc.tile_base, hp_pos, hp_nr, hp_r2, hp_wgt, hp_tao, n_hp, dstart, deps, g, nullptr, nullptr, 0u, nullptr, pc, cand, acc_n);
+        gather_tile<true>(pc.tile_base, hp_pos, hp_nr, hp_r2, hp_wgt, hp_tao, n_hp, dstart, dlen, deps, g, nullptr, nullptr, 0u, nullptr, pc, cand, acc_n);
         if (n <= n_waves) break;
         unsigned long long nx = 0;
         if (lane_id() == 0) nx = atomicAdd(next_piece, 1ull);
@@ -1010,6 +1037,60 @@ __global__ void __launch_bounds__(256) k_gather_split(const PosKey* __restrict__
         if (cand) atomicAdd(&counters->candidates, (unsigned long long)cand);
         if (acc_n) atomicAdd(&counters->accepted, (unsigned long long)acc_n);
     }
+}
+
+// Room per bucket for direct placement, from the deposit histogram of a batch: the count plus a margin that a
+// Poisson count of the same mean all but never exceeds; nothing for a bucket no HitPoint can reach (its deposits
+// are not stored).  slack_sigma = 0 leaves no margin (tests use it to send deposits down the overflow path).
+__global__ void k_bucket_room(const uint32_t* __restrict__ count, const uint8_t* __restrict__ occ, uint32_t n, float slack_sigma, uint32_t slack_add,
+                              uint32_t* __restrict__ room) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = count[i];
+    room[i] = occ[i] ? c + (uint32_t)ceilf(slack_sigma * sqrtf((float)c)) + slack_add : 0u;
+}
+
+// The same update as the gather's, from the deposit's side, for the few deposits that found their bucket full: one
+// wave per deposit walks the HitPoints of the 27 cells around it (the HitPoint array is sorted by bucket: hstart).
+__global__ void __launch_bounds__(256) k_gather_overflow(const Deposit* __restrict__ over, const unsigned long long* n_over, unsigned long long over_cap,
+                                                         unsigned long long* over_max, const uint32_t* __restrict__ hstart, const PosKey* __restrict__ hp_pos,
+                                                         const float4* __restrict__ hp_nr, const double* __restrict__ hp_r2,
+                                                         const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, GridParams g,
+                                                         DevCounters* counters) {
+    const unsigned long long n = min(*n_over, over_cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(over_max, n);   // the host drops a layout that overflows much
+    const unsigned long long n_waves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    const int lane = lane_id();
+    unsigned long long cand = 0, acc = 0;
+    for (unsigned long long i = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n; i += n_waves) {
+        const PosKey a = over[i].a;
+        const DepB b = over[i].b;
+        for (int c = 0; c < 27; c++) {
+            const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
+            const uint64_t key = a.key + ((uint64_t)(int64_t)dx << 42) + ((uint64_t)(int64_t)dy << 21) + (uint64_t)(int64_t)dz;
+            const uint32_t bk = key_bucket(key, g.mask);
+            const uint32_t s = hstart[bk], e = hstart[bk + 1];
+            for (uint32_t h = s + (uint32_t)lane; h < e; h += 64) {
+                const PosKey hp = hp_pos[h];
+                if (hp.key != key) continue;                    // another cell hashed into this bucket
+                const double vx = hp.x - a.x, vy = hp.y - a.y, vz = hp.z - a.z;
+                const double d2 = vx * vx + vy * vy + vz * vz;
+                if (!(d2 < SPPM_INIT_R2)) continue;
+                cand++;
+                const float4 nr = hp_nr[h];
+                if (!(nr.x * b.nx + nr.y * b.ny + nr.z * b.nz > 1e-3f) || !(d2 <= hp_r2[h])) continue;
+                acc++;
+                const float4 w = hp_wgt[h];
+                float* t = (float*)&hp_tao[h];
+                atomicAdd(t + 0, w.x * (b.fr * (float)SPPM_PI_INV));
+                atomicAdd(t + 1, w.y * (b.fg * (float)SPPM_PI_INV));
+                atomicAdd(t + 2, w.z * (b.fb * (float)SPPM_PI_INV));
+                atomicAdd((int*)(t + 3), 1);
+            }
+        }
+    }
+    if (cand) atomicAdd(&counters->candidates, cand);
+    if (acc) atomicAdd(&counters->accepted, acc);
 }
 
 // ------------------------------------------------------------------ resolve (Raytracer.h:281-293)
@@ -1185,6 +1266,13 @@ struct sppm_ctx {
     // photon pass
     DevBuf<Deposit> dep, sdep;   // deposits of a batch as traced / sorted by bucket
     DevBuf<GatherPiece> pieces;  // queued row ranges of heavy cells (k_gather -> k_gather_split)
+    // Direct placement of deposits (see TraceParams::place): the layout made from the histogram of an earlier batch
+    bool place_enabled = true;            // SPPM_PLACE=0: every batch is counting-sorted
+    float place_sigma = 6.0f; uint32_t place_add = 16;   // room of a bucket = count + sigma * sqrt(count) + add
+    bool place_valid = false;
+    uint32_t place_M = 0; uint64_t place_photons = 0, place_total = 0;
+    DevBuf<uint32_t> place_room, place_start;
+    DevBuf<unsigned long long> place_over_max;   // largest overflow list since the host last looked (one word)
     DevBuf<uint32_t> dstart, scan_partial;
     // Control block, one allocation so that one memset resets a pass: queue scalars (CTL_SCALARS x u64) |
     // gather tile counters (8 x 16 u32, 64 B apart) | {next, end} of the open output chunk of every trace wave slot
@@ -1296,6 +1384,8 @@ int sppm_create(sppm_ctx** out, int device_id) {
     if (const char* b = getenv("SPPM_EYE_BPC")) ctx->eye_blocks_per_cu = std::max(0, atoi(b));
     if (const char* b = getenv("SPPM_NEWTON_BPC")) ctx->newton_blocks_per_cu = std::max(1, atoi(b));
     if (const char* b = getenv("SPPM_DEP_FILTER")) ctx->dep_filter = atoi(b) != 0;
+    if (const char* b = getenv("SPPM_PLACE")) ctx->place_enabled = atoi(b) != 0;
+    if (const char* b = getenv("SPPM_PLACE_SIGMA")) { ctx->place_sigma = std::max(0.0f, (float)atof(b)); if (ctx->place_sigma == 0.0f) ctx->place_add = 0; }
     if (const char* b = getenv("SPPM_VERBOSE")) ctx->verbose = atoi(b) != 0;
     if (ctx->ctl.reserve(ctx->ctl_words()) != hipSuccess || ctx->counters.reserve(1) != hipSuccess) {
         (void)hipStreamDestroy(ctx->own_stream);
@@ -1318,6 +1408,7 @@ void sppm_destroy(sppm_ctx* ctx) {
     ctx->bucket_of.release(); ctx->hist.release(); ctx->hstart.release();
     ctx->hp_pos.release(); ctx->hp_nr.release(); ctx->hp_wgt.release(); ctx->hp_tao.release(); ctx->hp_meta.release(); ctx->hp_r2.release();
     ctx->dep.release(); ctx->sdep.release(); ctx->pieces.release();
+    ctx->place_room.release(); ctx->place_start.release(); ctx->place_over_max.release();
     ctx->dstart.release(); ctx->scan_partial.release(); ctx->ctl.release(); ctx->counters.release(); ctx->pic.release();
     if (ctx->host_pic) (void)hipHostFree(ctx->host_pic);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -1451,6 +1542,7 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
     HIPCHK(hipMemcpy(ctx->lights.p, dl.data(), dl.size() * sizeof(DevLight), hipMemcpyHostToDevice));
     ctx->n_lights = s->n_lights;
     ctx->has_dual_lobe = dual_lobe;
+    ctx->place_valid = false;
     ctx->have_scene = true;
     ctx->have_eye = false;
     return SPPM_OK;
@@ -1480,7 +1572,7 @@ static int launch_scan(sppm_ctx* ctx, const uint32_t* cnt, uint32_t* start, uint
 
 // queue scalars of the control block
 enum { SC_HITS = 0, SC_DEP = 1, SC_NEXT0 = 2 /* .. SC_NEXT0 + 3 */, SC_PARK0 = 6, SC_TASK0 = 7, SC_PARK1 = 8, SC_TASK1 = 9, SC_REAL_HITS = 10,
-       SC_PIECES = 11, SC_NEXT_PIECE = 12 };
+       SC_PIECES = 11, SC_NEXT_PIECE = 12, SC_OVER = 13 };
 
 // Smallest m >= want (>= 1) with gcd(m, n) = 1.
 static uint64_t coprime_near(uint64_t n, uint64_t want) {
@@ -1529,8 +1621,17 @@ struct QueueState { unsigned long long sc[CTL_SCALARS]; DevCounters dc; };
 static int read_queues(sppm_ctx* ctx, QueueState& q) {
     HIPCHK(hipMemcpyAsync(q.sc, ctx->scalars(), sizeof(q.sc), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(&q.dc, ctx->counters.p, sizeof(q.dc), hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long over_max = 0;
+    const bool look = ctx->place_valid && ctx->place_over_max.p;
+    if (look) HIPCHK(hipMemcpyAsync(&over_max, ctx->place_over_max.p, sizeof(over_max), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->check_pending = false;
+    // a deposit layout that sent many deposits to the overflow list no longer fits what is traced (another camera,
+    // other materials): the next batch is counting-sorted again and lays out a new one
+    if (look && over_max > 4096 && over_max > ctx->place_total / 64) {
+        ctx->place_valid = false;
+        HIPCHK(hipMemsetAsync(ctx->place_over_max.p, 0, sizeof(unsigned long long), ctx->stream));
+    }
     return SPPM_OK;
 }
 #define SPPM_RETRY_HITS (SPPM_E_CAPACITY + 100)
@@ -1678,7 +1779,12 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
     const uint64_t n = ctx->n_hp;
     const double cs = std::sqrt(SPPM_INIT_R2) * 1.0001;   // cell >= search radius: neighbours within +-1 cell
     ctx->grid.inv_cs = 1.0 / cs;
-    const uint32_t M = std::min<uint32_t>(1u << 22, std::max<uint32_t>(1u << 16, next_pow2(2 * std::max<uint64_t>(n, 1))));
+    uint32_t M = std::min<uint32_t>(1u << 22, std::max<uint32_t>(1u << 16, next_pow2(2 * std::max<uint64_t>(n, 1))));
+    // keep the bucket count of the last eye pass while it still suits (between 1.5 and 4 buckets per HitPoint): the
+    // deposit layout made for it stays usable when the HitPoint count wanders across a power of two
+    const uint32_t M_prev = ctx->grid.mask + 1;
+    if (ctx->place_valid && M_prev == ctx->place_M && M_prev >= (1u << 16) && 2 * (uint64_t)M_prev >= 3 * n && (uint64_t)M_prev <= 4 * std::max<uint64_t>(n, 1))
+        M = M_prev;
     ctx->grid.mask = M - 1;
     tic(ctx, PH_GRID);
     if (int rc = close_chunks(ctx, nullptr, ctx->raw.p, hit_cap)) return rc;
@@ -1712,6 +1818,7 @@ static void fill_photon_params(sppm_ctx* ctx, TraceParams& tp, uint32_t per_roun
     tp.dep = ctx->dep.p; tp.n_dep = ctx->scalars() + SC_DEP; tp.dep_cap = dep_cap;
     tp.dcount = ctx->dcount(); tp.grid = ctx->grid; tp.counters = counters;
     tp.occ = ctx->dep_filter ? ctx->occ() : nullptr;
+    tp.place = nullptr; tp.sorted = nullptr; tp.over = nullptr; tp.n_over = nullptr; tp.over_cap = 0;
     tp.wave_chunks = ctx->wave_chunks();
     tp.rng = host_rng_base(seed, replica * 4u + D_PHOTON);
 }
@@ -1783,25 +1890,44 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
         if (batch > (1ull << 24)) return fail(ctx, SPPM_E_INVALID, "more than 2^24 photons between two radius updates");
     }
     const uint64_t dep_cap = batch * (SPPM_MAX_DEP + 1) + dep_slack(ctx);
-    HIPCHK(ctx->dep.reserve(dep_cap)); HIPCHK(ctx->sdep.reserve(dep_cap));
+    HIPCHK(ctx->dep.reserve(dep_cap)); HIPCHK(ctx->sdep.reserve(std::max<uint64_t>(dep_cap, ctx->place_valid ? ctx->place_total : 0)));
+    HIPCHK(ctx->place_over_max.reserve(1));
     TraceParams tp{};
     fill_photon_params(ctx, tp, per_round, dep_cap, seed, replica, ctx->counters.p);
     QueueState q{};
     for (uint64_t first = photon_begin; first < end; first += batch) {
         const uint64_t count = std::min(batch, end - first);
         if (int rc = reset_ctl(ctx)) return rc;
-        if (int rc = launch_fill(ctx, ctx->cursor(), 2 * ((size_t)M + 1), 0)) return rc;   // cursor and dcount
-        tic(ctx, PH_TRACE);
-        bool synced = false;
-        if (int rc = run_trace(ctx, MODE_PHOTON, tp, first, count, false, false, q, &synced)) return rc;
-        if (int rc = close_chunks(ctx, ctx->dep.p, nullptr, dep_cap)) return rc;
-        toc(ctx);
-        tic(ctx, PH_SORT);
-        if (int rc = launch_scan(ctx, ctx->dcount(), ctx->dstart.p, M)) return rc;
-        hipLaunchKernelGGL(k_dep_scatter, dim3(ctx->num_cu * ctx->scatter_blocks_per_cu), dim3(256), 0, ctx->stream, ctx->dep.p, ctx->scalars() + SC_DEP,
-                           dep_cap, ctx->dstart.p, ctx->cursor(), ctx->sdep.p);
-        HIPCHK(hipGetLastError());
-        toc(ctx);
+        // Direct placement needs a layout made from a batch at least as large, on the same grid, and deposits
+        // filtered by reach (a bucket no HitPoint reaches has no room).
+        const bool placed = ctx->place_enabled && ctx->dep_filter && !sweeps && ctx->place_valid && ctx->place_M == M &&
+                            count <= ctx->place_photons && ctx->n_hp > 0;
+        const uint32_t* dstart = placed ? ctx->place_start.p : ctx->dstart.p;
+        const uint32_t* dlen = placed ? ctx->dcount() : nullptr;
+        if (placed) {
+            if (int rc = launch_fill(ctx, ctx->dcount(), (size_t)M + 1, 0)) return rc;
+            tp.place = ctx->place_start.p; tp.sorted = ctx->sdep.p;
+            // the overflow list is the buffer the counting sort would have read: it holds every deposit of a batch if it must
+            tp.over = ctx->dep.p; tp.n_over = ctx->scalars() + SC_OVER; tp.over_cap = dep_cap;
+            tic(ctx, PH_TRACE);
+            bool synced = false;
+            if (int rc = run_trace(ctx, MODE_PHOTON, tp, first, count, false, false, q, &synced)) return rc;
+            toc(ctx);
+        } else {
+            tp.place = nullptr;
+            if (int rc = launch_fill(ctx, ctx->cursor(), 2 * ((size_t)M + 1), 0)) return rc;   // cursor and dcount
+            tic(ctx, PH_TRACE);
+            bool synced = false;
+            if (int rc = run_trace(ctx, MODE_PHOTON, tp, first, count, false, false, q, &synced)) return rc;
+            if (int rc = close_chunks(ctx, ctx->dep.p, nullptr, dep_cap)) return rc;
+            toc(ctx);
+            tic(ctx, PH_SORT);
+            if (int rc = launch_scan(ctx, ctx->dcount(), ctx->dstart.p, M)) return rc;
+            hipLaunchKernelGGL(k_dep_scatter, dim3(ctx->num_cu * ctx->scatter_blocks_per_cu), dim3(256), 0, ctx->stream, ctx->dep.p, ctx->scalars() + SC_DEP,
+                               dep_cap, ctx->dstart.p, ctx->cursor(), ctx->sdep.p);
+            HIPCHK(hipGetLastError());
+            toc(ctx);
+        }
         if (ctx->n_hp > 0) {
             tic(ctx, PH_GATHER);
             const uint64_t tiles = (ctx->n_hp + GATHER_TILE - 1) / GATHER_TILE;
@@ -1809,11 +1935,15 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
             const uint32_t piece_cap = 1u << 20;
             HIPCHK(ctx->pieces.reserve(piece_cap));
             hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_r2.p, ctx->hp_wgt.p, ctx->hp_tao.p,
-                               (uint32_t)ctx->n_hp, ctx->dstart.p, ctx->sdep.p, ctx->grid, ctx->tile_ctr(), ctx->pieces.p,
+                               (uint32_t)ctx->n_hp, dstart, dlen, ctx->sdep.p, ctx->grid, ctx->tile_ctr(), ctx->pieces.p,
                                ctx->scalars() + SC_PIECES, piece_cap, ctx->counters.p);
             hipLaunchKernelGGL(k_gather_split, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_r2.p, ctx->hp_wgt.p,
-                               ctx->hp_tao.p, (uint32_t)ctx->n_hp, ctx->dstart.p, ctx->sdep.p, ctx->grid, ctx->pieces.p,
+                               ctx->hp_tao.p, (uint32_t)ctx->n_hp, dstart, dlen, ctx->sdep.p, ctx->grid, ctx->pieces.p,
                                ctx->scalars() + SC_PIECES, piece_cap, ctx->scalars() + SC_NEXT_PIECE, ctx->counters.p);
+            if (placed)   // the deposits that found their bucket full (normally none: the kernel looks at the count and leaves)
+                hipLaunchKernelGGL(k_gather_overflow, dim3(64), dim3(256), 0, ctx->stream, ctx->dep.p, ctx->scalars() + SC_OVER,
+                                   (unsigned long long)dep_cap, ctx->place_over_max.p, ctx->hstart.p, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_r2.p, ctx->hp_wgt.p,
+                                   ctx->hp_tao.p, ctx->grid, ctx->counters.p);
             HIPCHK(hipGetLastError());
             toc(ctx);
             ctx->gather_launches++;
@@ -1822,6 +1952,22 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
                                    ctx->hp_meta.p, (uint32_t)ctx->n_hp);
                 HIPCHK(hipGetLastError());
             }
+        }
+        // A counting-sorted batch of full size leaves its histogram behind: lay out the room for the batches to come
+        // (one wait for the stream, for the total; later batches and passes of this size are placed directly).
+        if (!placed && ctx->place_enabled && ctx->dep_filter && !sweeps && ctx->n_hp > 0 && count == batch) {
+            HIPCHK(ctx->place_room.reserve((size_t)M + 1)); HIPCHK(ctx->place_start.reserve((size_t)M + 1));
+            hipLaunchKernelGGL(k_bucket_room, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, ctx->dcount(), ctx->occ(), M, ctx->place_sigma,
+                               ctx->place_add, ctx->place_room.p);
+            HIPCHK(hipGetLastError());
+            if (int rc = launch_scan(ctx, ctx->place_room.p, ctx->place_start.p, M)) return rc;
+            uint32_t total_room = 0;
+            HIPCHK(hipMemsetAsync(ctx->place_over_max.p, 0, sizeof(unsigned long long), ctx->stream));
+            HIPCHK(hipMemcpyAsync(&total_room, ctx->place_start.p + M, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            ctx->place_total = total_room; ctx->place_M = M; ctx->place_photons = count; ctx->place_valid = true;
+            HIPCHK(ctx->sdep.reserve(std::max<uint64_t>(dep_cap, ctx->place_total)));
+            tp.sorted = ctx->sdep.p;
         }
     }
     return SPPM_OK;   // queued; a queue overflow, if any, is reported by the next call that waits for the stream

@@ -390,3 +390,61 @@ def test_parked_newton_path_gives_the_same_pass(gpu):
     pa, pb = gpu.resolve(), parked.resolve()
     assert np.allclose(pa, pb, rtol=1e-3, atol=1e-5 * pa.mean())
     parked.close()
+
+
+# ------------------------------------------------------------------ direct placement of deposits
+def _pass_state(ctx, cam, rounds, replica):
+    ctx.eye_pass(cam, SEED, replica)
+    ctx.photon_pass(rounds, 100, SEED, replica)
+    hp = ctx.hitpoints()
+    hp = hp[np.argsort(_key(hp))]
+    return hp, ctx.counters(), ctx.timings()
+
+
+def _same_pass(a, b):
+    (ha, ca, _), (hb, cb, _) = a, b
+    assert ca == cb and ca["accepted"] > 0
+    assert np.array_equal(_key(ha), _key(hb)) and np.array_equal(ha["newN"], hb["newN"])
+    assert np.allclose(ha["tao"], hb["tao"], rtol=1e-4, atol=1e-6 * ha["tao"].mean())
+
+
+@pytest.mark.parametrize("sigma", [None, "0"])
+def test_direct_placement_matches_the_counting_sort(sigma):
+    """After one counting-sorted batch a context places the deposits of later batches of that size straight into
+    per-bucket room laid out from that batch's histogram; deposits that find their bucket full are gathered from the
+    deposit's side.  Every pass equals the one of a context that always sorts (SPPM_PLACE=0): same counters, same
+    per-HitPoint photon counts.  With SPPM_PLACE_SIGMA=0 the room is the old count exactly, so a good part of the
+    deposits takes the overflow path; a camera somewhere else makes the whole layout wrong, and still nothing changes."""
+    scene = scenes.scene_teapot(1)
+    cam, cam_far = scenes.default_camera(120, 90), scenes.look_at((50, 40, 140), (50, 38, 900), 120, 90)   # turned round, down the open end of the tunnel
+    env = {"SPPM_PLACE": "0"}
+    os.environ.update(env)
+    try:
+        ref = SppmContext(0)
+    finally:
+        del os.environ["SPPM_PLACE"]
+    if sigma is not None:
+        os.environ["SPPM_PLACE_SIGMA"] = sigma
+    try:
+        ctx = SppmContext(0)
+    finally:
+        os.environ.pop("SPPM_PLACE_SIGMA", None)
+    try:
+        ref.set_scene(scene)
+        ctx.set_scene(scene)
+        sorts = []
+        for replica, c in enumerate([cam, cam, cam, cam_far, cam_far, cam]):
+            a = _pass_state(ctx, c, 400, replica)
+            sorts.append(a[2]["deposit_sort_ms"] > 0)
+            _same_pass(a, _pass_state(ref, c, 400, replica))
+        assert sorts[0] and not sorts[1]                 # the first pass lays the room out, the second is placed
+        if sigma is None:
+            # the far camera is first traced with the old layout (nearly all overflow), which the next eye pass sees
+            # and drops: that pass is sorted and lays the room out anew
+            assert sorts == [True, False, False, False, True, False], sorts
+        # a larger batch than the layout was made for is counting-sorted again
+        a = _pass_state(ctx, cam, 800, 9)
+        assert a[2]["deposit_sort_ms"] > 0
+        _same_pass(a, _pass_state(ref, cam, 800, 9))
+    finally:
+        ctx.close(); ref.close()
