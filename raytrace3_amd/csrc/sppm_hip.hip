@@ -225,6 +225,7 @@ struct TraceParams {
     // laid out from the histogram of an earlier batch of the same size; a deposit goes straight to
     // sorted[place[b] + (its rank among the deposits of b)], the rank being the value the histogram atomic returns,
     // and the counting sort is not needed.  A deposit that finds its bucket full goes to the list `over`.
+    uint32_t* dcount_all;                     // histogram of ALL diffuse hits, kept or not (null: not wanted); a layout is made from it
     const uint32_t* place;
     Deposit* sorted;
     Deposit* over; unsigned long long* n_over; unsigned long long over_cap;
@@ -507,6 +508,7 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
                     db.fr = carry[0]; db.fg = carry[1]; db.fb = carry[2];
                     const uint32_t bk = key_bucket(da.key, tp.grid.mask);
                     db.bucket = bk | (vertex << 24); db.photon = id;
+                    if (tp.dcount_all) atomicAdd(&tp.dcount_all[bk], 1u);
                     // no HitPoint in the 27 cells around: the gather would never look at this deposit
                     keep = !tp.occ || tp.occ[bk] != 0;
                 }
@@ -1039,15 +1041,17 @@ __global__ void __launch_bounds__(256) k_gather_split(const PosKey* __restrict__
     }
 }
 
-// Room per bucket for direct placement, from the deposit histogram of a batch: the count plus a margin that a
-// Poisson count of the same mean all but never exceeds; nothing for a bucket no HitPoint can reach (its deposits
-// are not stored).  slack_sigma = 0 leaves no margin (tests use it to send deposits down the overflow path).
-__global__ void k_bucket_room(const uint32_t* __restrict__ count, const uint8_t* __restrict__ occ, uint32_t n, float slack_sigma, uint32_t slack_add,
-                              uint32_t* __restrict__ room) {
+// Room per bucket for direct placement, from the histogram of ALL diffuse hits of a batch, reachable by a HitPoint
+// or not: which buckets are reachable changes with every camera jitter (HitPoints seen through the mirrors move far),
+// where the photons land does not.  Room = the count plus a margin that a Poisson count of the same mean all but
+// never exceeds; a bucket without a hit still gets a few slots (far down the open tunnel every batch hits other
+// cells, one photon each).  slack_sigma = 0 leaves no margin at all (tests use it to send deposits down the
+// overflow path).
+__global__ void k_bucket_room(const uint32_t* __restrict__ count, uint32_t n, float slack_sigma, uint32_t slack_add, uint32_t* __restrict__ room) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t c = count[i];
-    room[i] = occ[i] ? c + (uint32_t)ceilf(slack_sigma * sqrtf((float)c)) + slack_add : 0u;
+    room[i] = c ? c + (uint32_t)ceilf(slack_sigma * sqrtf((float)c)) + slack_add : (slack_add ? 8u : 0u);
 }
 
 // The same update as the gather's, from the deposit's side, for the few deposits that found their bucket full: one
@@ -1249,13 +1253,15 @@ struct sppm_ctx {
     int scatter_blocks_per_cu = 32;
     bool verbose = false;
     DevBuf<uint32_t> bucket_of, hstart;
-    // bucket occupancy bytes (M / 4 words) | HitPoint histogram | scatter cursors | deposit histogram ((M + 1) words each)
+    // bucket occupancy bytes (M / 4 words) | HitPoint histogram | scatter cursors | deposit histogram | histogram of all
+    // diffuse hits ((M + 1) words each)
     DevBuf<uint32_t> hist;
     size_t occ_words() const { return ((size_t)grid.mask + 1) / 4; }
     uint8_t* occ() const { return (uint8_t*)hist.p; }
     uint32_t* hcount() const { return hist.p + occ_words(); }
     uint32_t* cursor() const { return hcount() + ((size_t)grid.mask + 2); }
     uint32_t* dcount() const { return hcount() + 2 * ((size_t)grid.mask + 2); }
+    uint32_t* dcount_all() const { return hcount() + 3 * ((size_t)grid.mask + 2); }
     bool dep_filter = true;               // deposits no HitPoint can reach are not stored (SPPM_DEP_FILTER=0 keeps them)
     bool has_dual_lobe = false;           // some material reflects and refracts: eye paths branch
     DevBuf<PosKey> hp_pos; DevBuf<float4> hp_nr, hp_wgt, hp_tao; DevBuf<HpMeta> hp_meta; DevBuf<double> hp_r2;
@@ -1790,7 +1796,7 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
     if (int rc = close_chunks(ctx, nullptr, ctx->raw.p, hit_cap)) return rc;
     HIPCHK(ctx->bucket_of.reserve(std::max<uint64_t>(claimed, 1)));
     // hcount | cursor | dcount are one allocation: a pass clears two neighbours with one fill
-    HIPCHK(ctx->hist.reserve(ctx->occ_words() + 3 * ((size_t)M + 1)));
+    HIPCHK(ctx->hist.reserve(ctx->occ_words() + 4 * ((size_t)M + 1)));
     HIPCHK(ctx->hstart.reserve(M + 1)); HIPCHK(ctx->dstart.reserve(M + 1));
     HIPCHK(ctx->hp_pos.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_nr.reserve(std::max<uint64_t>(n, 1)));
     HIPCHK(ctx->hp_wgt.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_tao.reserve(std::max<uint64_t>(n, 1)));
@@ -1818,7 +1824,7 @@ static void fill_photon_params(sppm_ctx* ctx, TraceParams& tp, uint32_t per_roun
     tp.dep = ctx->dep.p; tp.n_dep = ctx->scalars() + SC_DEP; tp.dep_cap = dep_cap;
     tp.dcount = ctx->dcount(); tp.grid = ctx->grid; tp.counters = counters;
     tp.occ = ctx->dep_filter ? ctx->occ() : nullptr;
-    tp.place = nullptr; tp.sorted = nullptr; tp.over = nullptr; tp.n_over = nullptr; tp.over_cap = 0;
+    tp.place = nullptr; tp.sorted = nullptr; tp.over = nullptr; tp.n_over = nullptr; tp.over_cap = 0; tp.dcount_all = nullptr;
     tp.wave_chunks = ctx->wave_chunks();
     tp.rng = host_rng_base(seed, replica * 4u + D_PHOTON);
 }
@@ -1902,11 +1908,12 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
         // filtered by reach (a bucket no HitPoint reaches has no room).
         const bool placed = ctx->place_enabled && ctx->dep_filter && !sweeps && ctx->place_valid && ctx->place_M == M &&
                             count <= ctx->place_photons && ctx->n_hp > 0;
+        bool lay_out = false;     // this batch is counting-sorted and leaves a layout behind
         const uint32_t* dstart = placed ? ctx->place_start.p : ctx->dstart.p;
         const uint32_t* dlen = placed ? ctx->dcount() : nullptr;
         if (placed) {
             if (int rc = launch_fill(ctx, ctx->dcount(), (size_t)M + 1, 0)) return rc;
-            tp.place = ctx->place_start.p; tp.sorted = ctx->sdep.p;
+            tp.place = ctx->place_start.p; tp.sorted = ctx->sdep.p; tp.dcount_all = nullptr;
             // the overflow list is the buffer the counting sort would have read: it holds every deposit of a batch if it must
             tp.over = ctx->dep.p; tp.n_over = ctx->scalars() + SC_OVER; tp.over_cap = dep_cap;
             tic(ctx, PH_TRACE);
@@ -1915,7 +1922,9 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
             toc(ctx);
         } else {
             tp.place = nullptr;
-            if (int rc = launch_fill(ctx, ctx->cursor(), 2 * ((size_t)M + 1), 0)) return rc;   // cursor and dcount
+            lay_out = ctx->place_enabled && ctx->dep_filter && !sweeps && ctx->n_hp > 0 && count == batch;
+            tp.dcount_all = lay_out ? ctx->dcount_all() : nullptr;
+            if (int rc = launch_fill(ctx, ctx->cursor(), (lay_out ? 3 : 2) * ((size_t)M + 1), 0)) return rc;   // cursor, dcount (and dcount_all)
             tic(ctx, PH_TRACE);
             bool synced = false;
             if (int rc = run_trace(ctx, MODE_PHOTON, tp, first, count, false, false, q, &synced)) return rc;
@@ -1955,9 +1964,9 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
         }
         // A counting-sorted batch of full size leaves its histogram behind: lay out the room for the batches to come
         // (one wait for the stream, for the total; later batches and passes of this size are placed directly).
-        if (!placed && ctx->place_enabled && ctx->dep_filter && !sweeps && ctx->n_hp > 0 && count == batch) {
+        if (lay_out) {
             HIPCHK(ctx->place_room.reserve((size_t)M + 1)); HIPCHK(ctx->place_start.reserve((size_t)M + 1));
-            hipLaunchKernelGGL(k_bucket_room, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, ctx->dcount(), ctx->occ(), M, ctx->place_sigma,
+            hipLaunchKernelGGL(k_bucket_room, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, ctx->dcount_all(), M, ctx->place_sigma,
                                ctx->place_add, ctx->place_room.p);
             HIPCHK(hipGetLastError());
             if (int rc = launch_scan(ctx, ctx->place_room.p, ctx->place_start.p, M)) return rc;
@@ -2056,7 +2065,11 @@ int sppm_get_counters(sppm_ctx* ctx, sppm_counters* out) {
     if (ctx->verbose) {
         unsigned long long np = 0;
         (void)hipMemcpy(&np, ctx->scalars() + SC_PIECES, sizeof(np), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[sppm] gather pieces queued in the last batch: %llu\n", np);
+        unsigned long long nov = 0, omax = 0;
+        (void)hipMemcpy(&nov, ctx->scalars() + SC_OVER, sizeof(nov), hipMemcpyDeviceToHost);
+        if (ctx->place_over_max.p) (void)hipMemcpy(&omax, ctx->place_over_max.p, sizeof(omax), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[sppm] gather pieces queued in the last batch: %llu; deposits on the overflow list: %llu (largest since the last look %llu), "
+                        "layout %s, room for %llu deposits\n", np, nov, omax, ctx->place_valid ? "valid" : "none", (unsigned long long)ctx->place_total);
     }
     if (ctx->verbose && dc.stamps[0])
         fprintf(stderr, "[sppm] trace loop cycles: refill %llu analytic %llu bezier %llu merge/park %llu finish %llu bounce %llu loop %llu\n",

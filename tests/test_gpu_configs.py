@@ -414,7 +414,8 @@ def test_direct_placement_matches_the_counting_sort(sigma):
     per-bucket room laid out from that batch's histogram; deposits that find their bucket full are gathered from the
     deposit's side.  Every pass equals the one of a context that always sorts (SPPM_PLACE=0): same counters, same
     per-HitPoint photon counts.  With SPPM_PLACE_SIGMA=0 the room is the old count exactly, so a good part of the
-    deposits takes the overflow path; a camera somewhere else makes the whole layout wrong, and still nothing changes."""
+    deposits takes the overflow path.  A camera turned round sees other HitPoints and keeps other deposits; the layout,
+    made from every diffuse hit, serves it as well."""
     scene = scenes.scene_teapot(1)
     cam, cam_far = scenes.default_camera(120, 90), scenes.look_at((50, 40, 140), (50, 38, 900), 120, 90)   # turned round, down the open end of the tunnel
     env = {"SPPM_PLACE": "0"}
@@ -439,9 +440,8 @@ def test_direct_placement_matches_the_counting_sort(sigma):
             _same_pass(a, _pass_state(ref, c, 400, replica))
         assert sorts[0] and not sorts[1]                 # the first pass lays the room out, the second is placed
         if sigma is None:
-            # the far camera is first traced with the old layout (nearly all overflow), which the next eye pass sees
-            # and drops: that pass is sorted and lays the room out anew
-            assert sorts == [True, False, False, False, True, False], sorts
+            # the layout is made from where the photons land, not from what the camera sees: it outlives the turn
+            assert sorts == [True, False, False, False, False, False], sorts
         # a larger batch than the layout was made for is counting-sorted again
         a = _pass_state(ctx, cam, 800, 9)
         assert a[2]["deposit_sort_ms"] > 0
