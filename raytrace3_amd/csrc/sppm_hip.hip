@@ -2,7 +2,7 @@
 //
 // Pipeline of one replica:
 //   eye pass   : k_eye_trace (one lane per eye path, wave-cooperative Bezier Newton)
-//                -> raw HitPoints -> hashed grid: k_hp_count / k_scan / k_hp_scatter
+//                -> raw HitPoints (histogrammed by bucket as they are written) -> hashed grid: k_scan / k_hp_scatter / k_hp_occupancy
 //   photon pass: per batch  k_photon_trace (persistent wavefronts, lanes refilled from a
 //                photon counter; diffuse hits appended as deposit records, bucket
 //                histogram on the fly) -> k_scan -> k_dep_scatter (deposits sorted by
@@ -214,6 +214,7 @@ struct TraceParams {
     unsigned long long pix_mul;
     RawHit* hits; unsigned long long* n_hits; unsigned long long hit_cap;   // n_hits: claimed slots
     unsigned long long* n_real_hits;                                          // HitPoints written
+    uint32_t* hcount;                                                         // HitPoints per grid bucket (the histogram of their counting sort)
     // photon pass
     const DevLight* lights; int n_lights; uint32_t per_round;
     Deposit* dep; unsigned long long* n_dep; unsigned long long dep_cap;
@@ -484,8 +485,10 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
             const unsigned long long hs = chunk_alloc(emit_hp, slot_next, slot_end, tp.n_hits, TRACE_SLOT_CHUNK);
             if (emit_hp) {
                 nhit++;
-                if (hs < tp.hit_cap) tp.hits[hs] = rh;
-                else atomicOr(&tp.counters->overflow, 1u);
+                if (hs < tp.hit_cap) {
+                    tp.hits[hs] = rh;
+                    atomicAdd(&tp.hcount[key_bucket(cell_key(hit.pos, tp.grid.inv_cs), tp.grid.mask)], 1u);
+                } else atomicOr(&tp.counters->overflow, 1u);
             }
             const unsigned long long bs = wave_alloc(push, tp.n_park);
             if (push) {
@@ -634,15 +637,7 @@ __global__ void __launch_bounds__(256) k_newton(const ParkRec* __restrict__ park
 
 // ------------------------------------------------------------------ hashed grid over HitPoints
 // (replaces the flann kd-tree build, Raytracer.h:370-380)
-__global__ void k_hp_count(const RawHit* hits, uint32_t n, GridParams g, uint32_t* bucket_of, uint32_t* count) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (hits[i].pix < 0) { bucket_of[i] = 0xffffffffu; return; }   // a claimed but unused slot
-    uint64_t key = cell_key(ld3(hits[i].pos), g.inv_cs);
-    uint32_t b = key_bucket(key, g.mask);
-    bucket_of[i] = b;
-    atomicAdd(&count[b], 1u);
-}
+// The histogram of the HitPoints over the buckets is taken by the eye kernel as it writes them (TraceParams::hcount).
 
 // Exclusive prefix sum start[i] = sum_{j<i} cnt[j], i in [0, n], in three launches:
 // per-tile sums, a one-workgroup scan of the tile sums, per-tile scan + offset.
@@ -700,16 +695,16 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_final(const uint32_t* __r
     if (blockIdx.x == 0 && threadIdx.x == 0) start[n] = partial[nb];
 }
 
-__global__ void k_hp_scatter(const RawHit* hits, uint32_t n, GridParams g, const uint32_t* bucket_of, const uint32_t* start,
+__global__ void k_hp_scatter(const RawHit* hits, uint32_t n, GridParams g, const uint32_t* start,
                              uint32_t* cursor, PosKey* hp_pos, float4* hp_nr, float4* hp_wgt, float4* hp_tao, HpMeta* hp_meta,
                              double* hp_r2, int initial_n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t b = bucket_of[i];
-    if (b == 0xffffffffu) return;
     const RawHit h = hits[i];
-    uint32_t s = start[b] + atomicAdd(&cursor[b], 1u);
+    if (h.pix < 0) return;                              // a claimed but unused slot
     PosKey pk; pk.x = h.pos[0]; pk.y = h.pos[1]; pk.z = h.pos[2]; pk.key = cell_key(ld3(h.pos), g.inv_cs);
+    const uint32_t b = key_bucket(pk.key, g.mask);
+    uint32_t s = start[b] + atomicAdd(&cursor[b], 1u);
     hp_pos[s] = pk;
     hp_nr[s] = make_float4(h.n[0], h.n[1], h.n[2], 0.f);
     hp_r2[s] = SPPM_INIT_R2;                                                              // HitPoint(): R2 = INIT_R2, Raytracer.h:65
@@ -1252,7 +1247,8 @@ struct sppm_ctx {
     int eye_blocks_per_cu = 0;            // 0: as many trace workgroups as the pixels allow (up to 4 per CU)
     int scatter_blocks_per_cu = 32;
     bool verbose = false;
-    DevBuf<uint32_t> bucket_of, hstart;
+    DevBuf<uint32_t> hstart;
+    int grid_w = 0, grid_h = 0;           // resolution of the eye pass the bucket count was chosen for
     // bucket occupancy bytes (M / 4 words) | HitPoint histogram | scatter cursors | deposit histogram | histogram of all
     // diffuse hits ((M + 1) words each)
     DevBuf<uint32_t> hist;
@@ -1411,7 +1407,7 @@ void sppm_destroy(sppm_ctx* ctx) {
     ctx->pw_q.release(); ctx->pw_c.release();
     ctx->blob.release(); ctx->texels.release(); ctx->lights.release();
     ctx->raw.release(); ctx->park[0].release(); ctx->park[1].release(); ctx->ntask[0].release(); ctx->ntask[1].release(); ctx->nres.release();
-    ctx->bucket_of.release(); ctx->hist.release(); ctx->hstart.release();
+    ctx->hist.release(); ctx->hstart.release();
     ctx->hp_pos.release(); ctx->hp_nr.release(); ctx->hp_wgt.release(); ctx->hp_tao.release(); ctx->hp_meta.release(); ctx->hp_r2.release();
     ctx->dep.release(); ctx->sdep.release(); ctx->pieces.release();
     ctx->place_room.release(); ctx->place_start.release(); ctx->place_over_max.release();
@@ -1753,14 +1749,36 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
     const uint64_t npx = (uint64_t)cam->w * cam->h;
     uint64_t hit_cap = std::max<uint64_t>(2 * npx, 1 << 16) + dep_slack(ctx);
     if (!ctx->accumulate_stats) drop_spans(ctx);
+    // ---- the hashed grid the HitPoints will be sorted into.  The eye kernel histograms them as it writes them, so the
+    // bucket count is chosen BEFORE the trace, from the HitPoint count of the last eye pass at this resolution (a
+    // few per cent off at worst: the count only changes with the camera jitter) or else from the pixel count.  The
+    // bucket count of the last pass is kept while it still suits (1.5 to 4 buckets per HitPoint), so the deposit
+    // layout made for it stays usable when the count wanders across a power of two.  A count that suits badly costs
+    // hash collisions, not results.
+    const double cs = std::sqrt(SPPM_INIT_R2) * 1.0001;   // cell >= search radius: neighbours within +-1 cell
+    ctx->grid.inv_cs = 1.0 / cs;
+    {
+        const bool same = ctx->grid_w == cam->w && ctx->grid_h == cam->h && ctx->n_hp > 0;
+        const uint64_t n_est = same ? ctx->n_hp : npx;
+        const uint32_t M_prev = ctx->grid.mask + 1;
+        uint32_t M = std::min<uint32_t>(1u << 22, std::max<uint32_t>(1u << 16, next_pow2(2 * std::max<uint64_t>(n_est, 1))));
+        if (same && M_prev >= (1u << 16) && 2 * (uint64_t)M_prev >= 3 * n_est && (uint64_t)M_prev <= 4 * n_est) M = M_prev;
+        ctx->grid.mask = M - 1;
+        ctx->grid_w = cam->w; ctx->grid_h = cam->h;
+    }
+    const uint32_t M = ctx->grid.mask + 1;
+    HIPCHK(ctx->hist.reserve(ctx->occ_words() + 4 * ((size_t)M + 1)));
+    HIPCHK(ctx->hstart.reserve(M + 1)); HIPCHK(ctx->dstart.reserve(M + 1));
     QueueState q{};
     for (int attempt = 0;; attempt++) {
         HIPCHK(ctx->raw.reserve(hit_cap));
         // the tallies restart; the overflow flags stay until the host has looked at them
         if (!ctx->accumulate_stats) HIPCHK(hipMemsetAsync(ctx->counters.p, 0, offsetof(DevCounters, overflow), ctx->stream));
         if (int rc = reset_ctl(ctx)) return rc;
+        if (int rc = launch_fill(ctx, hist_words(ctx), ctx->occ_words() + 2 * ((size_t)M + 1), 0)) return rc;   // occupancy, hcount, cursor
         tic(ctx, PH_EYE);
         TraceParams tp{};
+        tp.hcount = ctx->hcount(); tp.grid = ctx->grid;
         for (int k = 0; k < 3; k++) { tp.pos[k] = cam->pos[k]; tp.dir[k] = cam->dir[k]; tp.du[k] = cam->du[k]; tp.dv[k] = cam->dv[k]; }
         tp.w = cam->w; tp.h = cam->h;
         tp.pix_mul = ctx->eye_scatter ? coprime_near(npx, (uint64_t)((double)npx * 0.6180339887)) : 1;
@@ -1781,32 +1799,17 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
     // q is the state after the last launch: claimed slots of the raw array (with holes) and the HitPoints in them
     const unsigned long long claimed = std::min<unsigned long long>(q.sc[SC_HITS], hit_cap);
     ctx->n_hp = q.sc[SC_REAL_HITS];
-    // ---- hashed grid over HitPoints
+    // ---- counting sort of the HitPoints by bucket (the histogram is the eye kernel's)
     const uint64_t n = ctx->n_hp;
-    const double cs = std::sqrt(SPPM_INIT_R2) * 1.0001;   // cell >= search radius: neighbours within +-1 cell
-    ctx->grid.inv_cs = 1.0 / cs;
-    uint32_t M = std::min<uint32_t>(1u << 22, std::max<uint32_t>(1u << 16, next_pow2(2 * std::max<uint64_t>(n, 1))));
-    // keep the bucket count of the last eye pass while it still suits (between 1.5 and 4 buckets per HitPoint): the
-    // deposit layout made for it stays usable when the HitPoint count wanders across a power of two
-    const uint32_t M_prev = ctx->grid.mask + 1;
-    if (ctx->place_valid && M_prev == ctx->place_M && M_prev >= (1u << 16) && 2 * (uint64_t)M_prev >= 3 * n && (uint64_t)M_prev <= 4 * std::max<uint64_t>(n, 1))
-        M = M_prev;
-    ctx->grid.mask = M - 1;
     tic(ctx, PH_GRID);
     if (int rc = close_chunks(ctx, nullptr, ctx->raw.p, hit_cap)) return rc;
-    HIPCHK(ctx->bucket_of.reserve(std::max<uint64_t>(claimed, 1)));
-    // hcount | cursor | dcount are one allocation: a pass clears two neighbours with one fill
-    HIPCHK(ctx->hist.reserve(ctx->occ_words() + 4 * ((size_t)M + 1)));
-    HIPCHK(ctx->hstart.reserve(M + 1)); HIPCHK(ctx->dstart.reserve(M + 1));
     HIPCHK(ctx->hp_pos.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_nr.reserve(std::max<uint64_t>(n, 1)));
     HIPCHK(ctx->hp_wgt.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_tao.reserve(std::max<uint64_t>(n, 1)));
     HIPCHK(ctx->hp_meta.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_r2.reserve(std::max<uint64_t>(n, 1)));
-    if (int rc = launch_fill(ctx, hist_words(ctx), ctx->occ_words() + 2 * ((size_t)M + 1), 0)) return rc;   // occupancy, hcount, cursor
     if (n > 0) {
         const int blocks = (int)((claimed + 255) / 256);
-        hipLaunchKernelGGL(k_hp_count, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)claimed, ctx->grid, ctx->bucket_of.p, ctx->hcount());
         if (int rc = launch_scan(ctx, ctx->hcount(), ctx->hstart.p, M)) return rc;
-        hipLaunchKernelGGL(k_hp_scatter, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)claimed, ctx->grid, ctx->bucket_of.p,
+        hipLaunchKernelGGL(k_hp_scatter, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)claimed, ctx->grid,
                            ctx->hstart.p, ctx->cursor(), ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->hp_tao.p, ctx->hp_meta.p,
                            ctx->hp_r2.p, ctx->initial_n);
         hipLaunchKernelGGL(k_hp_occupancy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->hp_pos.p, (uint32_t)n, ctx->grid, ctx->occ());
