@@ -1,16 +1,18 @@
 // sppm_hip.hip — HIP kernels (gfx950) and the C-ABI of include/sppm_abi.h.
 //
-// Pipeline of one replica:
-//   eye pass   : k_eye_trace (one lane per eye path, wave-cooperative Bezier Newton)
-//                -> raw HitPoints (histogrammed by bucket as they are written) -> hashed grid: k_scan / k_hp_scatter / k_hp_occupancy
-//   photon pass: per batch  k_photon_trace (persistent wavefronts, lanes refilled from a
-//                photon counter; diffuse hits appended as deposit records, bucket
-//                histogram on the fly) -> k_scan -> k_dep_scatter (deposits sorted by
-//                grid bucket) -> k_gather (one wave per tile of 64 sorted HitPoints,
-//                lanes stream the deposits of the 27 neighbour cells coalesced, the
-//                flux update is reduced across the wave and written by the tile's
-//                owner: no global atomics on HitPoints)
-//   resolve    : k_resolve (tao -> flux image)
+// Pipeline of one replica (everything is queued on the context's stream; the only host wait is the one of the
+// eye pass, which needs the HitPoint count):
+//   eye pass   : k_trace<MODE_EYE> (persistent waves, one lane per eye path, pixels dealt out in a scattered
+//                order, Bezier patches solved by the whole wave) -> raw HitPoints, histogrammed by grid bucket
+//                as they are written -> k_scan_* -> k_hp_scatter (HitPoints sorted by bucket) -> k_hp_occupancy
+//                (which buckets a HitPoint can reach)
+//   photon pass: per batch  k_trace<MODE_PHOTON> (lanes refilled from a photon counter; a diffuse hit that some
+//                HitPoint can reach becomes a deposit record) -> deposits grouped by bucket, either by
+//                k_scan_* + k_dep_scatter or, once a layout exists, written in place by the trace kernel itself
+//                -> k_gather (+ k_gather_split for heavy cells, k_gather_overflow for deposits that found their
+//                bucket full): the HitPoints of a cell share one sweep over the deposits of the 27 cells
+//                around them, rows of 64 deposits held in registers; no atomics on HitPoints in the main kernel
+//   resolve    : k_resolve (tao -> flux image) or k_film_add (-> fp64 image sum), k_tonemap
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
