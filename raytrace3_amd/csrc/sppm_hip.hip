@@ -9,8 +9,8 @@
 //   photon pass: per batch  k_trace<MODE_PHOTON> (lanes refilled from a photon counter; a diffuse hit that some
 //                HitPoint can reach becomes a deposit record) -> deposits grouped by bucket, either by
 //                k_scan_* + k_dep_scatter or, once a layout exists, written in place by the trace kernel itself
-//                -> k_gather (+ k_gather_split for heavy cells, k_gather_overflow for deposits that found their
-//                bucket full): the HitPoints of a cell share one sweep over the deposits of the 27 cells
+//                -> k_gather (+ k_gather_split for heavy cells and for deposits that found their bucket
+//                full): the HitPoints of a cell share one sweep over the deposits of the 27 cells
 //                around them, rows of 64 deposits held in registers; no atomics on HitPoints in the main kernel
 //   resolve    : k_resolve (tao -> flux image) or k_film_add (-> fp64 image sum), k_tonemap
 #include <hip/hip_runtime.h>
@@ -1012,52 +1012,14 @@ __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_po
     }
 }
 
-// The queued pieces of heavy cells (see GATHER_SPLIT_ROWS), one wave per piece at a time.
-__global__ void __launch_bounds__(256) k_gather_split(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
-                                                      const double* __restrict__ hp_r2, const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
-                                                      const uint32_t* __restrict__ dstart, const uint32_t* __restrict__ dlen,
-                                                      const Deposit* __restrict__ deps, GridParams g,
-                                                      const GatherPiece* __restrict__ pieces, const unsigned long long* __restrict__ n_pieces,
-                                                      uint32_t piece_cap, unsigned long long* next_piece, DevCounters* counters) {
-    const unsigned long long n = min(*n_pieces, (unsigned long long)piece_cap);
-    const unsigned long long n_waves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
-    uint32_t cand = 0, acc_n = 0;
-    // wave w starts with piece w; only when there are more pieces than waves does the shared counter come into
-    // play (a launch with nothing queued costs no atomic at all)
-    for (unsigned long long i = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n;) {
-        const GatherPiece pc = pieces[i];
-        gather_tile<true>(pc.tile_base, hp_pos, hp_nr, hp_r2, hp_wgt, hp_tao, n_hp, dstart, dlen, deps, g, nullptr, nullptr, 0u, nullptr, pc, cand, acc_n);
-        if (n <= n_waves) break;
-        unsigned long long nx = 0;
-        if (lane_id() == 0) nx = atomicAdd(next_piece, 1ull);
-        i = n_waves + bcast_u64(nx, 0);
-    }
-    if (lane_id() == 0) {
-        if (cand) atomicAdd(&counters->candidates, (unsigned long long)cand);
-        if (acc_n) atomicAdd(&counters->accepted, (unsigned long long)acc_n);
-    }
-}
-
-// Room per bucket for direct placement, from the histogram of ALL diffuse hits of a batch, reachable by a HitPoint
-// or not: which buckets are reachable changes with every camera jitter (HitPoints seen through the mirrors move far),
-// where the photons land does not.  Room = the count plus a margin that a Poisson count of the same mean all but
-// never exceeds; a bucket without a hit still gets a few slots (far down the open tunnel every batch hits other
-// cells, one photon each).  slack_sigma = 0 leaves no margin at all (tests use it to send deposits down the
-// overflow path).
-__global__ void k_bucket_room(const uint32_t* __restrict__ count, uint32_t n, float slack_sigma, uint32_t slack_add, uint32_t* __restrict__ room) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t c = count[i];
-    room[i] = c ? c + (uint32_t)ceilf(slack_sigma * sqrtf((float)c)) + slack_add : (slack_add ? 8u : 0u);
-}
-
 // The same update as the gather's, from the deposit's side, for the few deposits that found their bucket full: one
 // wave per deposit walks the HitPoints of the 27 cells around it (the HitPoint array is sorted by bucket: hstart).
-__global__ void __launch_bounds__(256) k_gather_overflow(const Deposit* __restrict__ over, const unsigned long long* n_over, unsigned long long over_cap,
-                                                         unsigned long long* over_max, const uint32_t* __restrict__ hstart, const PosKey* __restrict__ hp_pos,
-                                                         const float4* __restrict__ hp_nr, const double* __restrict__ hp_r2,
-                                                         const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, GridParams g,
-                                                         DevCounters* counters) {
+// Runs at the end of k_gather_split, whose waves use atomics on the HitPoints as well.
+__device__ __forceinline__ void gather_overflow(const Deposit* __restrict__ over, const unsigned long long* n_over, unsigned long long over_cap,
+                                                unsigned long long* over_max, const uint32_t* __restrict__ hstart, const PosKey* __restrict__ hp_pos,
+                                                const float4* __restrict__ hp_nr, const double* __restrict__ hp_r2,
+                                                const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, GridParams g,
+                                                DevCounters* counters) {
     const unsigned long long n = min(*n_over, over_cap);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(over_max, n);   // the host drops a layout that overflows much
     const unsigned long long n_waves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
@@ -1092,6 +1054,49 @@ __global__ void __launch_bounds__(256) k_gather_overflow(const Deposit* __restri
     }
     if (cand) atomicAdd(&counters->candidates, cand);
     if (acc) atomicAdd(&counters->accepted, acc);
+}
+
+// The queued pieces of heavy cells (see GATHER_SPLIT_ROWS), one wave per piece at a time.
+__global__ void __launch_bounds__(256) k_gather_split(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
+                                                      const double* __restrict__ hp_r2, const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
+                                                      const uint32_t* __restrict__ dstart, const uint32_t* __restrict__ dlen,
+                                                      const Deposit* __restrict__ deps, GridParams g,
+                                                      const GatherPiece* __restrict__ pieces, const unsigned long long* __restrict__ n_pieces,
+                                                      uint32_t piece_cap, unsigned long long* next_piece, DevCounters* counters,
+                                                      const Deposit* __restrict__ over, const unsigned long long* n_over,
+                                                      unsigned long long over_cap, unsigned long long* over_max,
+                                                      const uint32_t* __restrict__ hstart) {
+    const unsigned long long n = min(*n_pieces, (unsigned long long)piece_cap);
+    const unsigned long long n_waves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    uint32_t cand = 0, acc_n = 0;
+    // wave w starts with piece w; only when there are more pieces than waves does the shared counter come into
+    // play (a launch with nothing queued costs no atomic at all)
+    for (unsigned long long i = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n;) {
+        const GatherPiece pc = pieces[i];
+        gather_tile<true>(pc.tile_base, hp_pos, hp_nr, hp_r2, hp_wgt, hp_tao, n_hp, dstart, dlen, deps, g, nullptr, nullptr, 0u, nullptr, pc, cand, acc_n);
+        if (n <= n_waves) break;
+        unsigned long long nx = 0;
+        if (lane_id() == 0) nx = atomicAdd(next_piece, 1ull);
+        i = n_waves + bcast_u64(nx, 0);
+    }
+    if (lane_id() == 0) {
+        if (cand) atomicAdd(&counters->candidates, (unsigned long long)cand);
+        if (acc_n) atomicAdd(&counters->accepted, (unsigned long long)acc_n);
+    }
+    if (over) gather_overflow(over, n_over, over_cap, over_max, hstart, hp_pos, hp_nr, hp_r2, hp_wgt, hp_tao, g, counters);
+}
+
+// Room per bucket for direct placement, from the histogram of ALL diffuse hits of a batch, reachable by a HitPoint
+// or not: which buckets are reachable changes with every camera jitter (HitPoints seen through the mirrors move far),
+// where the photons land does not.  Room = the count plus a margin that a Poisson count of the same mean all but
+// never exceeds; a bucket without a hit still gets a few slots (far down the open tunnel every batch hits other
+// cells, one photon each).  slack_sigma = 0 leaves no margin at all (tests use it to send deposits down the
+// overflow path).
+__global__ void k_bucket_room(const uint32_t* __restrict__ count, uint32_t n, float slack_sigma, uint32_t slack_add, uint32_t* __restrict__ room) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = count[i];
+    room[i] = c ? c + (uint32_t)ceilf(slack_sigma * sqrtf((float)c)) + slack_add : (slack_add ? 8u : 0u);
 }
 
 // ------------------------------------------------------------------ resolve (Raytracer.h:281-293)
@@ -1953,11 +1958,10 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
                                ctx->scalars() + SC_PIECES, piece_cap, ctx->counters.p);
             hipLaunchKernelGGL(k_gather_split, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_r2.p, ctx->hp_wgt.p,
                                ctx->hp_tao.p, (uint32_t)ctx->n_hp, dstart, dlen, ctx->sdep.p, ctx->grid, ctx->pieces.p,
-                               ctx->scalars() + SC_PIECES, piece_cap, ctx->scalars() + SC_NEXT_PIECE, ctx->counters.p);
-            if (placed)   // the deposits that found their bucket full (normally none: the kernel looks at the count and leaves)
-                hipLaunchKernelGGL(k_gather_overflow, dim3(64), dim3(256), 0, ctx->stream, ctx->dep.p, ctx->scalars() + SC_OVER,
-                                   (unsigned long long)dep_cap, ctx->place_over_max.p, ctx->hstart.p, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_r2.p, ctx->hp_wgt.p,
-                                   ctx->hp_tao.p, ctx->grid, ctx->counters.p);
+                               ctx->scalars() + SC_PIECES, piece_cap, ctx->scalars() + SC_NEXT_PIECE, ctx->counters.p,
+                               // the deposits that found their bucket full (normally a handful) ride along
+                               placed ? (const Deposit*)ctx->dep.p : (const Deposit*)nullptr, ctx->scalars() + SC_OVER, (unsigned long long)dep_cap,
+                               ctx->place_over_max.p, ctx->hstart.p);
             HIPCHK(hipGetLastError());
             toc(ctx);
             ctx->gather_launches++;
