@@ -641,8 +641,8 @@ __global__ void __launch_bounds__(256) k_newton(const ParkRec* __restrict__ park
 // (replaces the flann kd-tree build, Raytracer.h:370-380)
 // The histogram of the HitPoints over the buckets is taken by the eye kernel as it writes them (TraceParams::hcount).
 
-// Exclusive prefix sum start[i] = sum_{j<i} cnt[j], i in [0, n], in three launches:
-// per-tile sums, a one-workgroup scan of the tile sums, per-tile scan + offset.
+// Exclusive prefix sum start[i] = sum_{j<i} cnt[j], i in [0, n], in two launches:
+// per-tile sums, then per-tile scan + the sum of the tiles before.
 #define SCAN_THREADS 256
 #define SCAN_PER_THREAD 8
 #define SCAN_TILE (SCAN_THREADS * SCAN_PER_THREAD)
@@ -664,37 +664,35 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
     if (total) *total = tot;
     return base + inc - v;
 }
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_reduce(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* __restrict__ partial) {
-    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+__device__ __forceinline__ void scan_reduce_tile(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* __restrict__ partial, uint32_t tile) {
+    const uint32_t base = tile * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
     uint32_t s = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_PER_THREAD; k++) if (base + k < n) s += cnt[base + k];
     uint32_t tot;
     block_exclusive_scan_256(s, &tot);
-    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+    if (threadIdx.x == 0) partial[tile] = tot;
 }
-// nb <= SCAN_TILE tile sums, exclusive-scanned in place; partial[nb] = grand total.
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_partials(uint32_t* partial, uint32_t nb) {
-    const uint32_t base = threadIdx.x * SCAN_PER_THREAD;
-    uint32_t v[SCAN_PER_THREAD], s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; k++) { v[k] = (base + k < nb) ? partial[base + k] : 0; s += v[k]; }
-    uint32_t tot;
-    uint32_t run = block_exclusive_scan_256(s, &tot);
-#pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; k++) { if (base + k < nb) partial[base + k] = run; run += v[k]; }
-    if (threadIdx.x == 0) partial[nb] = tot;
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_reduce(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* __restrict__ partial) {
+    scan_reduce_tile(cnt, n, partial, blockIdx.x);
 }
+// partial[]: the tile sums of k_scan_reduce (nb <= SCAN_TILE of them).  Every workgroup adds up the sums of the tiles
+// before its own (at most 8 loads per thread), so no third launch is needed to scan them.
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan_final(const uint32_t* __restrict__ cnt, uint32_t n, const uint32_t* __restrict__ partial,
                                                              uint32_t nb, uint32_t* __restrict__ start) {
+    uint32_t before = 0;
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += SCAN_THREADS) before += partial[j];
+    uint32_t offset;
+    block_exclusive_scan_256(before, &offset);           // offset = sum over the workgroup
     const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
     uint32_t v[SCAN_PER_THREAD], s = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_PER_THREAD; k++) { v[k] = (base + k < n) ? cnt[base + k] : 0; s += v[k]; }
-    uint32_t run = block_exclusive_scan_256(s, nullptr) + partial[blockIdx.x];
+    uint32_t tile_total;
+    uint32_t run = block_exclusive_scan_256(s, &tile_total) + offset;
 #pragma unroll
     for (int k = 0; k < SCAN_PER_THREAD; k++) { if (base + k < n) start[base + k] = run; run += v[k]; }
-    if (blockIdx.x == 0 && threadIdx.x == 0) start[n] = partial[nb];
+    if (blockIdx.x == nb - 1 && threadIdx.x == 0) start[n] = offset + tile_total;
 }
 
 __global__ void k_hp_scatter(const RawHit* hits, uint32_t n, GridParams g, const uint32_t* start,
@@ -765,8 +763,9 @@ __global__ void k_dep_scatter(const Deposit* __restrict__ dep, const unsigned lo
 
 // Marks the unused tail of every wave slot's open chunk as holes (run once per eye pass / photon batch,
 // after the last trace launch, before the records are sorted).  Exactly one of dep / hits is set.
-__global__ void k_close_chunks(const unsigned long long* __restrict__ wave_chunks, uint32_t n_slots, Deposit* dep, RawHit* hits, unsigned long long cap) {
-    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+__device__ __forceinline__ void close_chunks_block(const unsigned long long* __restrict__ wave_chunks, uint32_t n_slots, Deposit* dep, RawHit* hits,
+                                                   unsigned long long cap, uint32_t block) {
+    const uint32_t w = (block * blockDim.x + threadIdx.x) >> 6;
     if (w >= n_slots) return;
     const unsigned long long a = wave_chunks[2 * w], b = wave_chunks[2 * w + 1];
     for (unsigned long long h = a + lane_id(); h < b; h += 64)
@@ -774,6 +773,17 @@ __global__ void k_close_chunks(const unsigned long long* __restrict__ wave_chunk
             if (dep) dep[h].b.bucket = DEP_HOLE;
             else hits[h].pix = -1;
         }
+}
+__global__ void k_close_chunks(const unsigned long long* __restrict__ wave_chunks, uint32_t n_slots, Deposit* dep, RawHit* hits, unsigned long long cap) {
+    close_chunks_block(wave_chunks, n_slots, dep, hits, cap, blockIdx.x);
+}
+// The first launch of a scan and the closing of the open chunks, which have nothing to do with each other but the
+// place in the queue: the first nb workgroups sum histogram tiles, the others mark chunk tails.
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_reduce_close(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* __restrict__ partial, uint32_t nb,
+                                                                    const unsigned long long* __restrict__ wave_chunks, uint32_t n_slots, Deposit* dep,
+                                                                    RawHit* hits, unsigned long long cap) {
+    if (blockIdx.x < nb) scan_reduce_tile(cnt, n, partial, blockIdx.x);
+    else close_chunks_block(wave_chunks, n_slots, dep, hits, cap, blockIdx.x - nb);
 }
 
 // ------------------------------------------------------------------ gather
@@ -1147,6 +1157,13 @@ __global__ void k_tonemap(const double* film, int w, int h, double n_images, int
 
 __global__ void k_fill_u32(uint32_t* p, size_t n, uint32_t v) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+// Zeroes up to three ranges of 32-bit words in one launch (the control block, the tallies and the histograms of a pass).
+__global__ void k_zero3(uint32_t* p0, size_t n0, uint32_t* p1, size_t n1, uint32_t* p2, size_t n2) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (size_t i = t; i < n0; i += stride) p0[i] = 0u;
+    for (size_t i = t; i < n1; i += stride) p1[i] = 0u;
+    for (size_t i = t; i < n2; i += stride) p2[i] = 0u;
 }
 
 // ------------------------------------------------------------------ parity hooks
@@ -1565,13 +1582,32 @@ static int launch_fill(sppm_ctx* ctx, uint32_t* p, size_t n, uint32_t v) {
     return SPPM_OK;
 }
 
+// The control block, optionally the tallies, and a range of histogram words, zeroed by one launch at the start of a pass.
+static int launch_pass_reset(sppm_ctx* ctx, bool tallies, uint32_t* hist, size_t hist_words) {
+    const size_t ctl_w = ctx->ctl_words() * 2;                        // 64-bit scalars
+    const size_t tally_w = tallies ? offsetof(DevCounters, overflow) / 4 : 0;
+    const size_t most = std::max(std::max(ctl_w, tally_w), hist_words);
+    const int blocks = (int)std::min<size_t>((most + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_zero3, dim3(blocks), dim3(256), 0, ctx->stream, (uint32_t*)ctx->ctl.p, ctl_w, (uint32_t*)ctx->counters.p, tally_w,
+                       hist, hist_words);
+    HIPCHK(hipGetLastError());
+    return SPPM_OK;
+}
+
 // start[0..n] = exclusive prefix sums of cnt[0..n-1]; n <= SCAN_TILE^2.
-static int launch_scan(sppm_ctx* ctx, const uint32_t* cnt, uint32_t* start, uint32_t n) {
+static int trace_max_blocks(const sppm_ctx* ctx);
+// close_dep / close_hits: also turn the unused tails of the open chunks of that array into holes (see close_chunks).
+static int launch_scan(sppm_ctx* ctx, const uint32_t* cnt, uint32_t* start, uint32_t n, Deposit* close_dep = nullptr, RawHit* close_hits = nullptr,
+                       uint64_t close_cap = 0) {
     const uint32_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (nb > SCAN_TILE) return fail(ctx, SPPM_E_INVALID, "scan too large");
     HIPCHK(ctx->scan_partial.reserve(SCAN_TILE + 1));
+    if (close_dep || close_hits) {
+        const uint32_t n_slots = (uint32_t)trace_max_blocks(ctx) * 4u;
+        hipLaunchKernelGGL(k_scan_reduce_close, dim3(nb + (n_slots + 3) / 4), dim3(SCAN_THREADS), 0, ctx->stream, cnt, n, ctx->scan_partial.p, nb,
+                           ctx->wave_chunks(), n_slots, close_dep, close_hits, (unsigned long long)close_cap);
+    } else
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, ctx->stream, cnt, n, ctx->scan_partial.p);
-    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, ctx->scan_partial.p, nb);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, ctx->stream, cnt, n, ctx->scan_partial.p, nb, start);
     HIPCHK(hipGetLastError());
     return SPPM_OK;
@@ -1780,9 +1816,7 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
     for (int attempt = 0;; attempt++) {
         HIPCHK(ctx->raw.reserve(hit_cap));
         // the tallies restart; the overflow flags stay until the host has looked at them
-        if (!ctx->accumulate_stats) HIPCHK(hipMemsetAsync(ctx->counters.p, 0, offsetof(DevCounters, overflow), ctx->stream));
-        if (int rc = reset_ctl(ctx)) return rc;
-        if (int rc = launch_fill(ctx, hist_words(ctx), ctx->occ_words() + 2 * ((size_t)M + 1), 0)) return rc;   // occupancy, hcount, cursor
+        if (int rc = launch_pass_reset(ctx, !ctx->accumulate_stats, hist_words(ctx), ctx->occ_words() + 2 * ((size_t)M + 1))) return rc;   // + occupancy, hcount, cursor
         tic(ctx, PH_EYE);
         TraceParams tp{};
         tp.hcount = ctx->hcount(); tp.grid = ctx->grid;
@@ -1809,13 +1843,12 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
     // ---- counting sort of the HitPoints by bucket (the histogram is the eye kernel's)
     const uint64_t n = ctx->n_hp;
     tic(ctx, PH_GRID);
-    if (int rc = close_chunks(ctx, nullptr, ctx->raw.p, hit_cap)) return rc;
     HIPCHK(ctx->hp_pos.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_nr.reserve(std::max<uint64_t>(n, 1)));
     HIPCHK(ctx->hp_wgt.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_tao.reserve(std::max<uint64_t>(n, 1)));
     HIPCHK(ctx->hp_meta.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_r2.reserve(std::max<uint64_t>(n, 1)));
     if (n > 0) {
         const int blocks = (int)((claimed + 255) / 256);
-        if (int rc = launch_scan(ctx, ctx->hcount(), ctx->hstart.p, M)) return rc;
+        if (int rc = launch_scan(ctx, ctx->hcount(), ctx->hstart.p, M, nullptr, ctx->raw.p, hit_cap)) return rc;   // + chunk tails -> holes
         hipLaunchKernelGGL(k_hp_scatter, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)claimed, ctx->grid,
                            ctx->hstart.p, ctx->cursor(), ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->hp_tao.p, ctx->hp_meta.p,
                            ctx->hp_r2.p, ctx->initial_n);
@@ -1913,7 +1946,6 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
     QueueState q{};
     for (uint64_t first = photon_begin; first < end; first += batch) {
         const uint64_t count = std::min(batch, end - first);
-        if (int rc = reset_ctl(ctx)) return rc;
         // Direct placement needs a layout made from a batch at least as large, on the same grid, and deposits
         // filtered by reach (a bucket no HitPoint reaches has no room).
         const bool placed = ctx->place_enabled && ctx->dep_filter && !sweeps && ctx->place_valid && ctx->place_M == M &&
@@ -1922,7 +1954,7 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
         const uint32_t* dstart = placed ? ctx->place_start.p : ctx->dstart.p;
         const uint32_t* dlen = placed ? ctx->dcount() : nullptr;
         if (placed) {
-            if (int rc = launch_fill(ctx, ctx->dcount(), (size_t)M + 1, 0)) return rc;
+            if (int rc = launch_pass_reset(ctx, false, ctx->dcount(), (size_t)M + 1)) return rc;
             tp.place = ctx->place_start.p; tp.sorted = ctx->sdep.p; tp.dcount_all = nullptr;
             // the overflow list is the buffer the counting sort would have read: it holds every deposit of a batch if it must
             tp.over = ctx->dep.p; tp.n_over = ctx->scalars() + SC_OVER; tp.over_cap = dep_cap;
@@ -1934,14 +1966,13 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
             tp.place = nullptr;
             lay_out = ctx->place_enabled && ctx->dep_filter && !sweeps && ctx->n_hp > 0 && count == batch;
             tp.dcount_all = lay_out ? ctx->dcount_all() : nullptr;
-            if (int rc = launch_fill(ctx, ctx->cursor(), (lay_out ? 3 : 2) * ((size_t)M + 1), 0)) return rc;   // cursor, dcount (and dcount_all)
+            if (int rc = launch_pass_reset(ctx, false, ctx->cursor(), (lay_out ? 3 : 2) * ((size_t)M + 1))) return rc;   // + cursor, dcount (and dcount_all)
             tic(ctx, PH_TRACE);
             bool synced = false;
             if (int rc = run_trace(ctx, MODE_PHOTON, tp, first, count, false, false, q, &synced)) return rc;
-            if (int rc = close_chunks(ctx, ctx->dep.p, nullptr, dep_cap)) return rc;
             toc(ctx);
             tic(ctx, PH_SORT);
-            if (int rc = launch_scan(ctx, ctx->dcount(), ctx->dstart.p, M)) return rc;
+            if (int rc = launch_scan(ctx, ctx->dcount(), ctx->dstart.p, M, ctx->dep.p, nullptr, dep_cap)) return rc;   // + chunk tails -> holes
             hipLaunchKernelGGL(k_dep_scatter, dim3(ctx->num_cu * ctx->scatter_blocks_per_cu), dim3(256), 0, ctx->stream, ctx->dep.p, ctx->scalars() + SC_DEP,
                                dep_cap, ctx->dstart.p, ctx->cursor(), ctx->sdep.p);
             HIPCHK(hipGetLastError());
