@@ -1312,6 +1312,7 @@ struct sppm_ctx {
     bool check_pending = false;           // launches since the last look at the overflow flags
     DevBuf<float> pic;
     float* host_pic = nullptr; size_t host_pic_n = 0;   // pinned staging area of sppm_resolve
+    void* host_q = nullptr;               // pinned landing area of read_queues (copies into pageable memory would each block the host)
     uint64_t last_rounds = 0, last_per_round = 0;
     uint64_t batch = 1u << 22;            // photons traced, sorted and gathered together (128 B of deposit buffers per photon x 14)
     // HIP-event spans on the stream, read back (and only then waited for) by sppm_get_timings
@@ -1437,6 +1438,7 @@ void sppm_destroy(sppm_ctx* ctx) {
     ctx->place_room.release(); ctx->place_start.release(); ctx->place_over_max.release();
     ctx->dstart.release(); ctx->scan_partial.release(); ctx->ctl.release(); ctx->counters.release(); ctx->pic.release();
     if (ctx->host_pic) (void)hipHostFree(ctx->host_pic);
+    if (ctx->host_q) (void)hipHostFree(ctx->host_q);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -1664,15 +1666,21 @@ static int launch_trace_mode(sppm_ctx* ctx, int mode, bool coop, int blocks, con
 // What the host reads back when it has to look at the queues.
 struct QueueState { unsigned long long sc[CTL_SCALARS]; DevCounters dc; };
 static int read_queues(sppm_ctx* ctx, QueueState& q) {
-    HIPCHK(hipMemcpyAsync(q.sc, ctx->scalars(), sizeof(q.sc), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(&q.dc, ctx->counters.p, sizeof(q.dc), hipMemcpyDeviceToHost, ctx->stream));
-    unsigned long long over_max = 0;
+    struct Landing { QueueState q; unsigned long long over_max; };
+    if (!ctx->host_q) HIPCHK(hipHostMalloc(&ctx->host_q, sizeof(Landing), hipHostMallocDefault));
+    Landing* L = (Landing*)ctx->host_q;
+    L->over_max = 0;
+    // three small copies queued back to back into pinned memory, one wait
+    HIPCHK(hipMemcpyAsync(L->q.sc, ctx->scalars(), sizeof(L->q.sc), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&L->q.dc, ctx->counters.p, sizeof(L->q.dc), hipMemcpyDeviceToHost, ctx->stream));
     const bool look = ctx->place_valid && ctx->place_over_max.p;
-    if (look) HIPCHK(hipMemcpyAsync(&over_max, ctx->place_over_max.p, sizeof(over_max), hipMemcpyDeviceToHost, ctx->stream));
+    if (look) HIPCHK(hipMemcpyAsync(&L->over_max, ctx->place_over_max.p, sizeof(L->over_max), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    q = L->q;
+    const unsigned long long over_max = L->over_max;
     ctx->check_pending = false;
-    // a deposit layout that sent many deposits to the overflow list no longer fits what is traced (another camera,
-    // other materials): the next batch is counting-sorted again and lays out a new one
+    // a deposit layout that sent many deposits to the overflow list no longer fits what is traced (another scene
+    // behind the same grid, other materials): the next batch is counting-sorted again and lays out a new one
     if (look && over_max > 4096 && over_max > ctx->place_total / 64) {
         ctx->place_valid = false;
         HIPCHK(hipMemsetAsync(ctx->place_over_max.p, 0, sizeof(unsigned long long), ctx->stream));
