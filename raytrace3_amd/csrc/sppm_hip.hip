@@ -831,7 +831,9 @@ __device__ __forceinline__ float wave_total_f(float v) {
 static_assert(GATHER_SPLIT_ROWS % GATHER_ROWS == 0 && GATHER_OWN_ROWS % GATHER_ROWS == 0, "a sweep is cut between passes of GATHER_ROWS rows");
 struct GatherPiece { uint32_t tile_base, lead, row_begin, row_end; };   // lead: lane of one HitPoint of the cell in its tile
 
-template <bool PIECE>
+// FIXED_R2: every HitPoint still has R2 = INIT_R2 (the reference's case: update() never runs), so `dist^2 <= R2` is
+// implied by the search radius test and the radii are not even loaded.
+template <bool PIECE, bool FIXED_R2>
 __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
                                             const double* __restrict__ hp_r2,
                                             const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, const uint32_t n_hp,
@@ -845,7 +847,7 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
     const bool valid = (uint32_t)lane < GATHER_TILE && mine < n_hp;
     const PosKey mp = hp_pos[valid ? mine : base];
     const float4 mnr = hp_nr[valid ? mine : base];
-    const double mr2 = hp_r2[valid ? mine : base];
+    const double mr2 = FIXED_R2 ? SPPM_INIT_R2 : hp_r2[valid ? mine : base];
     const float4 mw = hp_wgt[valid ? mine : base];
     float tr = 0, tg = 0, tb = 0;
     uint32_t tn = 0;
@@ -926,7 +928,7 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
                 gm &= gm - 1;
                 const double hx = bcast_d(mp.x, j), hy = bcast_d(mp.y, j), hz = bcast_d(mp.z, j);
                 const float nx = bcast_f(mnr.x, j), ny = bcast_f(mnr.y, j), nz = bcast_f(mnr.z, j);
-                const double R2 = bcast_d(mr2, j);
+                const double R2 = FIXED_R2 ? SPPM_INIT_R2 : bcast_d(mr2, j);
                 const float wr = bcast_f(mw.x, j), wg = bcast_f(mw.y, j), wb = bcast_f(mw.z, j);
                 float pr = 0, pg = 0, pb = 0;
                 uint32_t pn = 0;
@@ -937,12 +939,13 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
                         const double d2 = vx * vx + vy * vy + vz * vz;
                         const bool c = d2 < SPPM_INIT_R2;      // flann radiusSearch(radius = searchR2): strict '<' on the squared distance
                         const float dn = nx * bnx[r] + ny * bny[r] + nz * bnz[r];
-                        const bool facing = dn > 1e-3f, inr = d2 <= R2;
+                        const bool facing = dn > 1e-3f, inr = FIXED_R2 ? true : (d2 <= R2);
                         const bool ok = c & facing & inr;
                         // ballots of the bare compares, combined as scalars (a ballot of their conjunction costs two more vector instructions)
                         const uint64_t cm = __builtin_amdgcn_ballot_w64(c);
                         cand += (uint32_t)__popcll(cm);
-                        pn += (uint32_t)__popcll(cm & __builtin_amdgcn_ballot_w64(facing) & __builtin_amdgcn_ballot_w64(inr));
+                        pn += FIXED_R2 ? (uint32_t)__popcll(cm & __builtin_amdgcn_ballot_w64(facing))
+                                       : (uint32_t)__popcll(cm & __builtin_amdgcn_ballot_w64(facing) & __builtin_amdgcn_ballot_w64(inr));
                         if (ok) {   // three FMAs under the lane mask (no per-channel select)
                             pr = fmaf(wr, bfr[r], pr);
                             pg = fmaf(wg, bfg[r], pg);
@@ -995,6 +998,7 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
 // workgroup starts on the eighth of its XCD (workgroups are dealt round-robin to the 8 XCDs), so the
 // tiles in flight on one XCD are neighbours in bucket order and share its L2, and moves on to the
 // other eighths when its own is drained (tile cost varies with the photon density around it).
+template <bool FIXED_R2>
 __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
                                                 const double* __restrict__ hp_r2, const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
                                                 const uint32_t* __restrict__ dstart, const uint32_t* __restrict__ dlen,
@@ -1012,7 +1016,7 @@ __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_po
             if (lane_id() == 0) t = atomicAdd(&tile_ctr[q * 16], 1u);
             t = bcast_u(t, 0) + q * per;
             if (t >= q_end) break;
-            gather_tile<false>(t * GATHER_TILE, hp_pos, hp_nr, hp_r2, hp_wgt, hp_tao, n_hp, dstart, dlen, deps, g, pieces, n_pieces, piece_cap,
+            gather_tile<false, FIXED_R2>(t * GATHER_TILE, hp_pos, hp_nr, hp_r2, hp_wgt, hp_tao, n_hp, dstart, dlen, deps, g, pieces, n_pieces, piece_cap,
                                &counters->overflow, GatherPiece{0, 0, 0, 0}, cand, acc_n);
         }
     }
@@ -1067,6 +1071,7 @@ __device__ __forceinline__ void gather_overflow(const Deposit* __restrict__ over
 }
 
 // The queued pieces of heavy cells (see GATHER_SPLIT_ROWS), one wave per piece at a time.
+template <bool FIXED_R2>
 __global__ void __launch_bounds__(256) k_gather_split(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
                                                       const double* __restrict__ hp_r2, const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
                                                       const uint32_t* __restrict__ dstart, const uint32_t* __restrict__ dlen,
@@ -1083,7 +1088,7 @@ __global__ void __launch_bounds__(256) k_gather_split(const PosKey* __restrict__
     // play (a launch with nothing queued costs no atomic at all)
     for (unsigned long long i = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n;) {
         const GatherPiece pc = pieces[i];
-        gather_tile<true>(pc.tile_base, hp_pos, hp_nr, hp_r2, hp_wgt, hp_tao, n_hp, dstart, dlen, deps, g, nullptr, nullptr, 0u, nullptr, pc, cand, acc_n);
+        gather_tile<true, FIXED_R2>(pc.tile_base, hp_pos, hp_nr, hp_r2, hp_wgt, hp_tao, n_hp, dstart, dlen, deps, g, nullptr, nullptr, 0u, nullptr, pc, cand, acc_n);
         if (n <= n_waves) break;
         unsigned long long nx = 0;
         if (lane_id() == 0) nx = atomicAdd(next_piece, 1ull);
@@ -1285,6 +1290,7 @@ struct sppm_ctx {
     bool dep_filter = true;               // deposits no HitPoint can reach are not stored (SPPM_DEP_FILTER=0 keeps them)
     bool has_dual_lobe = false;           // some material reflects and refracts: eye paths branch
     DevBuf<PosKey> hp_pos; DevBuf<float4> hp_nr, hp_wgt, hp_tao; DevBuf<HpMeta> hp_meta; DevBuf<double> hp_r2;
+    bool radii_changed = false;           // an update() sweep has run on the HitPoints of the last eye pass: R2 != INIT_R2 for some
     int initial_n = 0;                    // HitPoint::N at creation (the reference: 0, which keeps update() from ever running)
     uint32_t rounds_per_update = 1;       // with initial_n > 0: rounds of a photon pass between two update() sweeps
     uint64_t n_hp = 0;
@@ -1865,6 +1871,7 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
     }
     toc(ctx);
     ctx->have_eye = true;
+    ctx->radii_changed = false;
     ctx->last_rounds = 0; ctx->last_per_round = 0;
     return SPPM_OK;
 }
@@ -1992,21 +1999,25 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
             const int blocks = (int)std::max<uint64_t>(8, std::min<uint64_t>((uint64_t)ctx->num_cu * ctx->gather_blocks_per_cu, ((tiles + 3) / 4 + 7) / 8 * 8));
             const uint32_t piece_cap = 1u << 20;
             HIPCHK(ctx->pieces.reserve(piece_cap));
-            hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_r2.p, ctx->hp_wgt.p, ctx->hp_tao.p,
-                               (uint32_t)ctx->n_hp, dstart, dlen, ctx->sdep.p, ctx->grid, ctx->tile_ctr(), ctx->pieces.p,
-                               ctx->scalars() + SC_PIECES, piece_cap, ctx->counters.p);
-            hipLaunchKernelGGL(k_gather_split, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_r2.p, ctx->hp_wgt.p,
-                               ctx->hp_tao.p, (uint32_t)ctx->n_hp, dstart, dlen, ctx->sdep.p, ctx->grid, ctx->pieces.p,
-                               ctx->scalars() + SC_PIECES, piece_cap, ctx->scalars() + SC_NEXT_PIECE, ctx->counters.p,
-                               // the deposits that found their bucket full (normally a handful) ride along
-                               placed ? (const Deposit*)ctx->dep.p : (const Deposit*)nullptr, ctx->scalars() + SC_OVER, (unsigned long long)dep_cap,
-                               ctx->place_over_max.p, ctx->hstart.p);
+            // the deposits that found their bucket full (normally a handful) ride along with the pieces
+            const Deposit* over = placed ? (const Deposit*)ctx->dep.p : (const Deposit*)nullptr;
+#define SPPM_LAUNCH_GATHER(FIXED)                                                                                                                        \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<FIXED>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_r2.p,            \
+                       ctx->hp_wgt.p, ctx->hp_tao.p, (uint32_t)ctx->n_hp, dstart, dlen, ctx->sdep.p, ctx->grid, ctx->tile_ctr(), ctx->pieces.p,         \
+                       ctx->scalars() + SC_PIECES, piece_cap, ctx->counters.p);                                                                          \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_split<FIXED>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_r2.p,      \
+                       ctx->hp_wgt.p, ctx->hp_tao.p, (uint32_t)ctx->n_hp, dstart, dlen, ctx->sdep.p, ctx->grid, ctx->pieces.p,                          \
+                       ctx->scalars() + SC_PIECES, piece_cap, ctx->scalars() + SC_NEXT_PIECE, ctx->counters.p, over, ctx->scalars() + SC_OVER,           \
+                       (unsigned long long)dep_cap, ctx->place_over_max.p, ctx->hstart.p)
+            if (!sweeps && !ctx->radii_changed) { SPPM_LAUNCH_GATHER(true); } else { SPPM_LAUNCH_GATHER(false); }
+#undef SPPM_LAUNCH_GATHER
             HIPCHK(hipGetLastError());
             toc(ctx);
             ctx->gather_launches++;
             if (sweeps) {
                 hipLaunchKernelGGL(k_hp_update, dim3((unsigned)((ctx->n_hp + 255) / 256)), dim3(256), 0, ctx->stream, ctx->hp_r2.p, ctx->hp_tao.p,
                                    ctx->hp_meta.p, (uint32_t)ctx->n_hp);
+                ctx->radii_changed = true;
                 HIPCHK(hipGetLastError());
             }
         }
