@@ -77,6 +77,14 @@ def cpu_baseline(scene, w, h, rounds, threads):
 VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9      # CUs x SIMDs x lanes per cycle x 2.4 GHz: vector instructions per lane per second
 
 
+def _kernel(d, name):
+    """The summary's entry for a kernel, template arguments or not (k_gather, k_gather<true>)."""
+    for k, v in d.items():
+        if k == name or k.startswith(name + "<"):
+            return v
+    return {}
+
+
 def measured_valu():
     """Vector instructions per launch of the two dominant kernels from the committed PMC profile
     (SQ_INSTS_VALU, wave instructions): both kernels live on VALU issue, not on HBM."""
@@ -86,9 +94,9 @@ def measured_valu():
         try:
             with open(f) as fh:
                 d = json.load(fh)
-            g, t = d.get("k_gather", {}).get("SQ_INSTS_VALU"), d.get("k_trace<1, true>", {}).get("SQ_INSTS_VALU")
+            g, t = _kernel(d, "k_gather").get("SQ_INSTS_VALU"), d.get("k_trace<1, true>", {}).get("SQ_INSTS_VALU")
             if g and t:
-                g += d.get("k_gather_split", {}).get("SQ_INSTS_VALU") or 0.0
+                g += _kernel(d, "k_gather_split").get("SQ_INSTS_VALU") or 0.0
                 best = {"k_gather_wave_insts": float(g), "k_trace_photon_wave_insts": float(t), "source": "profiles/" + os.path.basename(f)}
         except (OSError, ValueError):
             pass
@@ -105,9 +113,9 @@ def measured_traffic():
         try:
             with open(f) as fh:
                 d = json.load(fh)
-            t = d.get("k_gather", {}).get("hbm_traffic_bytes_per_launch")
+            t = _kernel(d, "k_gather").get("hbm_traffic_bytes_per_launch")
             if t:      # the heavy-cell pieces are part of the same gather
-                t2 = d.get("k_gather_split", {}).get("hbm_traffic_bytes_per_launch") or 0.0
+                t2 = _kernel(d, "k_gather_split").get("hbm_traffic_bytes_per_launch") or 0.0
                 best = (float(t) + float(t2), os.path.basename(f))
         except (OSError, ValueError):
             pass
