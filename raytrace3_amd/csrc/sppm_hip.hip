@@ -1459,13 +1459,16 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
     if (s->n_objects <= 0 || !s->objects) return fail(ctx, SPPM_E_INVALID, "scene has no objects");
     if (s->n_lights <= 0 || !s->lights) return fail(ctx, SPPM_E_INVALID, "scene has no lights");
     if (s->n_patches < 0 || (s->n_patches > 0 && !s->patches)) return fail(ctx, SPPM_E_INVALID, "bad patch array");
+    if (s->n_textures < 0 || (s->n_textures > 0 && !s->textures)) return fail(ctx, SPPM_E_INVALID, "bad texture array");
+    if (s->n_patches > 64 * SPPM_MASK_WORDS) return fail(ctx, SPPM_E_CAPACITY, "more than 256 Bezier patches in one scene");
+    if (s->n_objects > 256) return fail(ctx, SPPM_E_CAPACITY, "more than 256 objects in one scene");
     HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // passes still queued read the tables replaced below
     const int no = s->n_objects, np = s->n_patches;
     const int off_box = (int)(((size_t)no * sizeof(DevObject) + 15) & ~(size_t)15);
     const int off_cp = off_box + np * 6 * (int)sizeof(double);
     const int off_pobj = off_cp + np * 48 * (int)sizeof(float);
     const int bytes = (off_pobj + np * (int)sizeof(int) + 15) & ~15;
-    if (np > 64 * SPPM_MASK_WORDS) return fail(ctx, SPPM_E_CAPACITY, "more than 256 Bezier patches in one scene");
     if (bytes > 64 * 1024) return fail(ctx, SPPM_E_CAPACITY, "scene tables exceed the 64 KiB LDS staging area (too many patches/objects)");
     std::vector<char> blob((size_t)bytes, 0);
     DevObject* objs = (DevObject*)blob.data();
@@ -1492,6 +1495,7 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
             return fail(ctx, SPPM_E_INVALID, "empty texture");
         td[t].rows = s->textures[t].rows; td[t].cols = s->textures[t].cols; td[t].offset = (unsigned)total; td[t].pad = 0;
         total += (size_t)td[t].rows * td[t].cols;
+        if (total > (1ull << 30)) return fail(ctx, SPPM_E_CAPACITY, "more than 2^30 texels in one scene");
     }
     bool dual_lobe = false;
     for (int i = 0; i < no; i++) {
@@ -1939,8 +1943,9 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
     if (!ctx->have_eye) return fail(ctx, SPPM_E_INVALID, "sppm_eye_pass must come first");
     if (rounds == 0 || per_round == 0) return fail(ctx, SPPM_E_INVALID, "rounds and per_round must be positive");
     HIPCHK(hipSetDevice(ctx->device));
-    const uint64_t total = rounds * (uint64_t)ctx->n_lights * per_round;
-    if (total > 0xffffffffull) return fail(ctx, SPPM_E_INVALID, "more than 2^32 photons in one pass");
+    if (rounds > 0xffffffffull) return fail(ctx, SPPM_E_INVALID, "more than 2^32 photons in one pass");
+    const uint64_t total = rounds * (uint64_t)ctx->n_lights * per_round;   // < 2^32 * 2^31 * 2^32: the product may wrap, the factors are checked first
+    if (total / per_round / (uint64_t)ctx->n_lights != rounds || total > 0xffffffffull) return fail(ctx, SPPM_E_INVALID, "more than 2^32 photons in one pass");
     if (photon_begin > total) return fail(ctx, SPPM_E_INVALID, "photon_begin beyond the pass");
     const uint64_t end = photon_count == 0 ? total : std::min(total, photon_begin + photon_count);
     ctx->last_rounds = rounds; ctx->last_per_round = per_round;
@@ -2182,7 +2187,9 @@ int sppm_debug_photon_deposits(sppm_ctx* ctx, uint64_t rounds, uint32_t per_roun
     if (!ctx || !n || (!out && cap)) return SPPM_E_INVALID;
     if (!ctx->have_eye) return fail(ctx, SPPM_E_INVALID, "sppm_eye_pass must come first");
     if (rounds == 0 || per_round == 0 || photon_count == 0) return fail(ctx, SPPM_E_INVALID, "empty photon range");
+    if (rounds > 0xffffffffull) return fail(ctx, SPPM_E_INVALID, "more than 2^32 photons in one pass");
     const uint64_t total = rounds * (uint64_t)ctx->n_lights * per_round;
+    if (total / per_round / (uint64_t)ctx->n_lights != rounds || total > 0xffffffffull) return fail(ctx, SPPM_E_INVALID, "more than 2^32 photons in one pass");
     if (photon_begin >= total) return fail(ctx, SPPM_E_INVALID, "photon_begin beyond the pass");
     const uint64_t count = std::min(photon_count, total - photon_begin);
     if (count > (1u << 22)) return fail(ctx, SPPM_E_INVALID, "at most 2^22 photons per debug call");

@@ -168,6 +168,37 @@ def test_c4_full_size_properties(gpu):
     _gpu_properties(gpu, rounds, per_round)
 
 
+def test_largest_scene_the_tables_hold(gpu):
+    """Seven teapots = 224 patches: the staged scene tables take 58 KiB of LDS and the photon kernel adds 12 KiB of
+    emission slices, the largest workgroup footprint a scene can ask for.  Both passes against the oracle; an eighth
+    teapot no longer fits the 64 KiB of tables, a ninth exceeds the 256 patches the patch masks can name."""
+    from raytrace3_amd.abi import SppmError
+
+    def with_teapots(extra):
+        s = scenes.scene_teapot(4)
+        for c in [(40, 30, 90), (72, 30, 100), (30, 45, 70), (75, 10, 95), (50, 20, 40)][:extra]:
+            s.add_bezier(c, 2, scenes.TEAPOT_BPT, (0, .999, .999), scenes.WHITE_DIFF, scenes.teapot_transform(), -1)
+        return s
+
+    scene, cam = with_teapots(3), scenes.default_camera(240, 135)
+    o = _run_pair(gpu, scene, cam, 10000, 100, 10_000)
+    g, c = gpu.hitpoints(), o.hitpoints()
+    gm, cm, n_common = _match(g, c)
+    assert n_common >= 0.995 * len(c)
+    same = gm["obj"] == cm["obj"]
+    assert same.mean() >= 0.995
+    assert (np.abs(gm["pos"] - cm["pos"]).max(axis=1)[same] <= 1e-3).mean() >= 0.97
+    assert gpu.counters()["photons"] == o.counters()["photons"] == 10_000
+    _image_parity(gpu.resolve(), o.resolve(), frac=0.95, mae=4e-3)
+    with pytest.raises(SppmError, match="64 KiB"):
+        gpu.set_scene(with_teapots(4))
+    with pytest.raises(SppmError, match="256 Bezier patches"):
+        gpu.set_scene(with_teapots(5))
+    gpu.set_scene(scene)          # the context is still usable after the refusals
+    gpu.eye_pass(cam, SEED)
+    assert len(gpu.hitpoints()) == len(g)
+
+
 # ------------------------------------------------------------------ config 5: glass ball caustic, 1024 x 1024, 50 M photons
 def test_c5_reduced_against_oracle(gpu):
     scene, cam = scenes.scene_caustic(), scenes.default_camera(256, 256)
