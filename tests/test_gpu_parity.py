@@ -308,6 +308,72 @@ def test_photon_sharding_and_batches(gpu):
     assert np.allclose(acc, a + b, rtol=1e-6, atol=0)
 
 
+def _random_room(rng, with_teapot):
+    """A closed room like the reference's (Scene.h:116-157) with everything else drawn at random: wall materials,
+    two to four spheres of any material (diffuse, mirror, glass, diffuse + mirror, diffuse + glass, mirror + glass:
+    the last one branches the eye paths), textures on some, one or two lights, optionally a teapot."""
+    s = scenes.FlatScene()
+    tex = [s.add_texture(scenes.procedural_texture(n, 64, 48)) for n in ("wall", "planet")]
+    both = scenes.material(refl=(.5, .5, .5), refr=(.45, .45, .45), refrn=1.4)
+    wall_mats = (scenes.WHITE_DIFF, scenes.WHITE_DIFF, scenes.WHITE_DIFF, scenes.MIRROR, scenes.MIRROR2)
+    ball_mats = (scenes.WHITE_DIFF, scenes.MIRROR, scenes.REFR0, scenes.REFR4, scenes.MIRROR2, both)
+    pick = lambda seq: seq[int(rng.integers(0, len(seq)))]
+    maybe_tex = lambda: pick(tex) if rng.random() < 0.4 else -1
+    s.add_plane((1, 40.8, 81.6), (1, 0, 0), rng.uniform(.2, .8, 3), pick(wall_mats), maybe_tex())
+    s.add_plane((99, 40.8, 81.6), (1, 0, 0), rng.uniform(.2, .8, 3), pick(wall_mats), maybe_tex())
+    s.add_plane((50, 40.8, 0), (0, 0, 1), rng.uniform(.2, .8, 3), pick(wall_mats), maybe_tex())
+    s.add_plane((50, 0, 81.6), (0, -1, 0), (.75, .75, .75), scenes.WHITE_DIFF, maybe_tex())        # the floor stays diffuse
+    s.add_plane((50, 81.6, 81.6), (0, 1, 0), rng.uniform(.2, .8, 3), pick(wall_mats), maybe_tex())
+    for _ in range(int(rng.integers(2, 5))):
+        r = float(rng.uniform(5, 15))
+        c = (float(rng.uniform(15, 85)), float(rng.uniform(r, 60)), float(rng.uniform(30, 140)))
+        s.add_sphere(r, c, rng.uniform(.5, .999, 3), pick(ball_mats), maybe_tex())
+    if with_teapot:
+        c = (float(rng.uniform(20, 70)), float(rng.uniform(0, 30)), float(rng.uniform(60, 130)))
+        s.add_bezier(c, float(rng.uniform(2, 4)), scenes.TEAPOT_BPT, (0, .999, .999), pick((scenes.WHITE_DIFF, scenes.MIRROR2)),
+                     scenes.teapot_transform(), maybe_tex())
+    for _ in range(int(rng.integers(1, 3))):
+        s.add_light((float(rng.uniform(20, 80)), float(rng.uniform(45, 75)), float(rng.uniform(40, 120))), (5000, 5000, 5000))
+    return s
+
+
+@pytest.mark.parametrize("with_teapot", [False, True])
+def test_random_rooms_whole_iteration(gpu, with_teapot):
+    """Eye pass, photon pass and resolve over rooms drawn at random, against the oracle: the same HitPoints (pixel and
+    node of the eye-path tree), the same tallies, the same image.  Analytic rooms to the analytic tolerances; with a
+    teapot to those of the Bezier tests (fp32 Newton on the GPU)."""
+    rng = np.random.default_rng(7 + int(with_teapot))
+    cam = scenes.default_camera(96, 72)
+    for trial in range(3 if with_teapot else 5):
+        s = _random_room(rng, with_teapot)
+        n_lights = len(s.light_list)
+        gpu.set_scene(s)
+        gpu.eye_pass(cam, SEED + trial)
+        gpu.photon_pass(150, 100, SEED + trial)
+        o = _oracle(s)
+        o.eye_pass(cam, SEED + trial)
+        o.photon_pass(150, 100, SEED + trial)
+        g, c = gpu.hitpoints(), o.hitpoints()
+        cg, co = gpu.counters(), o.counters()
+        assert cg["photons"] == co["photons"] == 150 * 100 * n_lights
+        img_g, img_c = gpu.resolve(), o.resolve()
+        mean = img_c.mean()
+        assert mean > 0, trial
+        diff = np.abs(img_g - img_c).max(axis=2) / mean
+        if not with_teapot:
+            assert np.array_equal(np.sort(_key(g)), np.sort(_key(c))), trial
+            for k in ("segments", "deposits", "candidates", "accepted", "eye_segments"):
+                assert cg[k] == pytest.approx(co[k], rel=2e-3), (trial, k)
+            assert (diff <= 1e-3).mean() >= 0.999 and diff.mean() <= 1e-5, (trial, (diff <= 1e-3).mean(), diff.mean())
+        else:
+            common = np.intersect1d(_key(g), _key(c))
+            assert len(common) >= 0.99 * len(c) and abs(len(g) - len(c)) <= 0.01 * len(c), (trial, len(g), len(c), len(common))
+            for k in ("segments", "deposits", "candidates", "accepted", "eye_segments"):
+                assert cg[k] == pytest.approx(co[k], rel=3e-2), (trial, k)
+            assert (diff <= 2e-3).mean() >= 0.99 and diff.mean() <= 1e-3, (trial, (diff <= 2e-3).mean(), diff.mean())
+        print(f"room {trial}: {len(c)} HitPoints, {co['deposits']} deposits, image within tolerance {(diff <= 1e-3).mean():.4f}, MAE/mean {diff.mean():.2e}")
+
+
 def test_empty_and_error_paths(gpu):
     from raytrace3_amd import SppmError
     fresh = SppmContext(0)
