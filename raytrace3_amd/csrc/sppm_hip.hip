@@ -539,6 +539,7 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
                 o = hit.pos; d = nd;
                 if (dep > SPPM_MAX_DEP) active = false;                                   // Raytracer.h:126-133
             }
+            STAMP(6);
             if (dp) ndep++;
             dp = dp && keep;
             if (tp.place) {
@@ -2136,8 +2137,8 @@ int sppm_get_counters(sppm_ctx* ctx, sppm_counters* out) {
                         "layout %s, room for %llu deposits\n", np, nov, omax, ctx->place_valid ? "valid" : "none", (unsigned long long)ctx->place_total);
     }
     if (ctx->verbose && dc.stamps[0])
-        fprintf(stderr, "[sppm] trace loop cycles: refill %llu analytic %llu bezier %llu merge/park %llu finish %llu bounce %llu loop %llu\n",
-                dc.stamps[0], dc.stamps[1], dc.stamps[2], dc.stamps[3], dc.stamps[4], dc.stamps[5], dc.stamps[7]);
+        fprintf(stderr, "[sppm] trace loop cycles: refill %llu analytic %llu bezier %llu merge/park %llu finish %llu bounce %llu (photons: %llu of them up to the new direction) loop %llu\n",
+                dc.stamps[0], dc.stamps[1], dc.stamps[2], dc.stamps[3], dc.stamps[4], dc.stamps[5] + dc.stamps[6], dc.stamps[6], dc.stamps[7]);
     ctx->check_pending = false;
     if (overflow_code(ctx, dc) != SPPM_OK) return fail(ctx, SPPM_E_CAPACITY, "a ray / task / deposit queue overflowed in an earlier pass");
     return SPPM_OK;
