@@ -479,3 +479,70 @@ def test_direct_placement_matches_the_counting_sort(sigma):
         _same_pass(a, _pass_state(ref, cam, 800, 9))
     finally:
         ctx.close(); ref.close()
+
+
+def test_a_reused_context_gives_what_fresh_contexts_give():
+    """One context taken through scenes, resolutions, batch shapes and the radius-update knob in turn: every pass equals
+    the pass of a context created for it alone (what a long-lived host relies on: the deposit layout, the bucket count kept
+    from the last eye pass, the radii and the histograms of earlier passes must not leak into the next)."""
+    teapot, balls = scenes.scene_teapot(1), scenes.scene_spheres_plane(True)
+    plan = [                                            # scene, (w, h), rounds, initial_n, passes in a row
+        (teapot, (96, 72), 300, 0, 3),                  # lays a deposit layout out, then uses it
+        (balls, (64, 48), 200, 0, 2),                   # another scene behind the same grid size
+        (balls, (64, 48), 200, 4, 1),                   # radius update on: sweeps shrink the radii
+        (balls, (64, 48), 200, 0, 2),                   # and off again: every radius back at its initial value
+        (teapot, (120, 90), 300, 0, 2),                 # more HitPoints than before
+        (teapot, (96, 72), 150, 0, 1),                  # fewer photons than the layout was made for
+    ]
+    worn = SppmContext(0)
+    try:
+        for step, (scene, (w, h), rounds, initial_n, passes) in enumerate(plan):
+            cam = scenes.default_camera(w, h)
+            fresh = SppmContext(0)
+            try:
+                for c in (worn, fresh):
+                    c.set_scene(scene)
+                    c.set_radius_update(initial_n, 50)
+                for k in range(passes):
+                    for c in (worn, fresh):
+                        c.eye_pass(cam, SEED, k)
+                        c.photon_pass(rounds, 100, SEED, k)
+                    a, b = worn.resolve(), fresh.resolve()
+                    ha, hb = worn.hitpoints(), fresh.hitpoints()
+                    assert len(ha) == len(hb) and int(ha["newN"].sum()) == int(hb["newN"].sum()), (step, k)
+                    assert np.array_equal(np.sort(ha["R2"]), np.sort(hb["R2"])), (step, k)
+                    ca, cb = worn.counters(), fresh.counters()
+                    assert all(ca[x] == cb[x] for x in ("photons", "segments", "deposits", "candidates", "accepted")), (step, k, ca, cb)
+                    assert b.sum() > 0 and np.allclose(a, b, rtol=2e-4, atol=1e-6 * b.mean()), (step, k)
+            finally:
+                fresh.close()
+    finally:
+        worn.close()
+
+
+def test_contexts_and_films_release_their_memory():
+    """Create, use and destroy contexts and films over and over: the GPU's free memory comes back."""
+    import torch
+    from raytrace3_amd import Film
+    scene, cam = scenes.scene_teapot(1), scenes.default_camera(160, 120)
+
+    def cycle():
+        g, film = SppmContext(0), Film(160, 120)
+        try:
+            g.set_scene(scene)
+            g.eye_pass(cam, SEED)
+            g.photon_pass(500, 100, SEED)
+            film.add(g)
+            assert film.read().sum() > 0
+        finally:
+            film.close()
+            g.close()
+
+    cycle()                                             # the runtime's own one-off allocations happen here
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(6):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, (free0, free1)
