@@ -59,7 +59,21 @@ class Bezier3Obj : public Obj {
 
 public:
     // File format (.bpt): patch count, then per patch "m n" and (m+1)(n+1) points; each
-    // point becomes Trans * (scale * p) + C.  Only bicubic patches (16 points) are accepted.
+    // point becomes Trans * (scale * p) + C.  The reference copies the points into Bezier3::P[16] as they come
+    // (raytracer/Bezier.h:205-224), which is a bicubic patch only for m = n = 3.  A patch of lower degree in u or v
+    // is raised to degree 3 here (degree elevation: the same surface, exactly); a higher degree has no bicubic form
+    // and the patch is skipped with a message.
+    static void elevate(Vec3 q[4], int& deg) {       // one Bezier curve, degree deg -> deg + 1
+        Vec3 r[4];
+        r[0] = q[0];
+        for (int i = 1; i <= deg; i++) {
+            const double a = (double)i / (deg + 1);
+            r[i] = q[i - 1] * a + q[i] * (1 - a);
+        }
+        r[deg + 1] = q[deg];
+        deg++;
+        for (int i = 0; i <= deg; i++) q[i] = r[i];
+    }
     Bezier3Obj(const Vec3& C, double scale, const std::string& file, const Color& cc, const Material& mm,
                const Mat33& Trans = Mat33::eye())
         : Obj(mm, cc) {
@@ -72,15 +86,26 @@ public:
         for (int i = 0; i < size && in; i++) {
             int m = 0, n = 0;
             in >> m >> n;
-            if ((m + 1) * (n + 1) > 16) { std::cerr << "Bezier3Obj: patch " << i << " is not bicubic, skipped" << std::endl; 
-                double skip; for (int k = 0; k < 3 * (m + 1) * (n + 1); k++) in >> skip; continue; }
-            Vec3 pts[16];
+            if (m < 0 || n < 0) { std::cerr << "Bezier3Obj: bad degrees in patch " << i << std::endl; return; }
+            if (m > 3 || n > 3) {
+                std::cerr << "Bezier3Obj: patch " << i << " has degree " << m << " x " << n << " (more than bicubic), skipped" << std::endl;
+                double skip; for (long k = 0; k < 3L * (m + 1) * (n + 1); k++) in >> skip; continue; }
+            Vec3 g[4][4];                               // g[j][k]: k runs along u (the fast index of P[16])
             for (int j = 0; j <= m; j++)
                 for (int k = 0; k <= n; k++) {
                     Vec3 p;
                     for (int l = 0; l < 3; l++) { in >> p.val[l]; p.val[l] *= scale; }
-                    pts[j * (n + 1) + k] = Trans * p;
+                    g[j][k] = Trans * p;
                 }
+            for (int j = 0; j <= m; j++) { int d = n; while (d < 3) elevate(g[j], d); }
+            for (int k = 0; k < 4; k++) {
+                Vec3 col[4];
+                for (int j = 0; j <= m; j++) col[j] = g[j][k];
+                int d = m; while (d < 3) elevate(col, d);
+                for (int j = 0; j < 4; j++) g[j][k] = col[j];
+            }
+            Vec3 pts[16];
+            for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++) pts[j * 4 + k] = g[j][k];
             for (int k = 0; k < 16; k++) { pts[k] += C; aabb.addpoint(pts[k]); }
             Bezier3 b;
             b.read(pts);

@@ -33,9 +33,24 @@ REFR0 = material(refr=(.999, .999, .999), refrn=1.5)
 REFR4 = material((.2, .2, .2), refr=(0, .5, .5), refrn=1.5)
 
 
+def _elevate(q, axis):
+    """Degree elevation of Bezier control points along one axis: the same curve with one more control point."""
+    q = np.moveaxis(q, axis, 0)
+    d = q.shape[0] - 1
+    r = np.empty((d + 2,) + q.shape[1:], dtype=np.float64)
+    r[0], r[d + 1] = q[0], q[d]
+    for i in range(1, d + 1):
+        a = i / (d + 1)
+        r[i] = q[i - 1] * a + q[i] * (1 - a)
+    return np.moveaxis(r, 0, axis)
+
+
 def load_bpt(path, C_=(0, 0, 0), scale=1.0, trans=None):
     """Bezier3Obj constructor, raytracer/Bezier.h:199-235: per patch `m n` then
-    (m+1)(n+1) points; point = Trans * (scale * p) + C.  Returns [n_patches, 16, 3]."""
+    (m+1)(n+1) points; point = Trans * (scale * p) + C.  Returns [n_patches, 16, 3].
+    The reference copies the points into Bezier3::P[16] as they come, which is a bicubic patch only for
+    m = n = 3; a patch of lower degree in u or v is raised to degree 3 here (degree elevation: the same
+    surface, exactly), a higher degree has no bicubic form and is refused."""
     trans = np.eye(3) if trans is None else np.asarray(trans, dtype=np.float64)
     with open(path) as f:
         tok = f.read().split()
@@ -44,13 +59,18 @@ def load_bpt(path, C_=(0, 0, 0), scale=1.0, trans=None):
     patches = np.zeros((size, 16, 3), dtype=np.float64)
     for i in range(size):
         m, n = int(next(it)), int(next(it))
-        if (m + 1) * (n + 1) > 16:
-            raise ValueError("only bicubic (3x3) patches fit Bezier3::P[16]")
+        if not (0 <= m <= 3 and 0 <= n <= 3):
+            raise ValueError(f"{path}: patch {i} has degree {m} x {n}; Bezier3::P[16] holds at most a bicubic patch")
+        g = np.zeros((m + 1, n + 1, 3))
         for j in range(m + 1):
             for k in range(n + 1):
                 p = np.array([float(next(it)) * scale for _ in range(3)])
-                patches[i, j * (n + 1) + k] = trans @ p
-        patches[i] += np.asarray(C_, dtype=np.float64)
+                g[j, k] = trans @ p
+        while g.shape[1] < 4:
+            g = _elevate(g, 1)
+        while g.shape[0] < 4:
+            g = _elevate(g, 0)
+        patches[i] = g.reshape(16, 3) + np.asarray(C_, dtype=np.float64)
     return patches
 
 

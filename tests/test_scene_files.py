@@ -51,3 +51,61 @@ def test_scene_file_errors(tmp_path):
              "plane p0=0,0,0 n=0,2,0 color=1,1,1 material=M texture=T\nlight pos=0,5,0 color=1,1,1\n")
     assert np.array_equal(s.texture_list[0], img)
     assert s.objects[0]["n"] == (0.0, 1.0, 0.0) and s.objects[0]["texture"] == 0     # PlaneObj normalises n
+
+
+def _bernstein(d, t):
+    from math import comb
+    return np.array([comb(d, i) * t ** i * (1 - t) ** (d - i) for i in range(d + 1)])
+
+
+def test_bpt_patches_of_lower_degree_are_raised_to_bicubic(tmp_path):
+    """A .bpt patch of degree m x n below 3 x 3 is the same surface after the loaders raise it to the bicubic form
+    Bezier3::P[16] stands for (raytracer/Bezier.h:69-111: P[4 j + k], k along u); the Python and the C++ loader give the
+    same control points; a degree above 3 is refused."""
+    import shutil
+    import subprocess
+    rng = np.random.default_rng(5)
+    degrees = [(2, 2), (1, 3), (3, 1), (0, 2), (3, 3)]
+    grids = [rng.normal(size=(m + 1, n + 1, 3)) * 5 for m, n in degrees]
+    path = tmp_path / "mixed.bpt"
+    with open(path, "w") as f:
+        f.write(f"{len(degrees)}\n")
+        for (m, n), g in zip(degrees, grids):
+            f.write(f"{m} {n}\n")
+            for j in range(m + 1):
+                for k in range(n + 1):
+                    f.write(" ".join(repr(float(x)) for x in g[j, k]) + "\n")
+    trans = scenes.teapot_transform()
+    patches = scenes.load_bpt(str(path), (1.0, 2.0, 3.0), 2.0, trans)
+    assert patches.shape == (len(degrees), 16, 3)
+    for (m, n), g, P in zip(degrees, grids, patches):
+        world = np.einsum("ab,jkb->jka", trans, 2.0 * g) + np.array([1.0, 2.0, 3.0])
+        for u, v in rng.random((20, 2)):
+            low = np.einsum("j,k,jkc->c", _bernstein(m, v), _bernstein(n, u), world)
+            cubic = np.einsum("j,k,jkc->c", _bernstein(3, v), _bernstein(3, u), P.reshape(4, 4, 3))
+            assert np.allclose(low, cubic, rtol=0, atol=1e-12), (m, n)
+    # a bicubic patch passes through as it is
+    assert np.allclose(patches[4], (np.einsum("ab,jkb->jka", trans, 2.0 * grids[4]) + [1.0, 2.0, 3.0]).reshape(16, 3), rtol=0, atol=1e-13)
+    # the C++ host's loader (include/raytrace3/Bezier.h) reads the same file into the same control points
+    if shutil.which("g++"):
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        src = tmp_path / "dump.cpp"
+        src.write_text('#include "Bezier.h"\n#include <cstdio>\n#include <cmath>\n'
+                       # Obj::GetIntersect goes through the library (defined in Scene.h); this program only loads a file
+                       'namespace sppm_host { Collision intersect_objects(const std::vector<Obj*>&, const Ray&) { return Collision(); } }\n'
+                       'int main(int, char** a) {\n'
+                       '  cv::Matx33d T, T2; T(0,0)=1; T(1,2)=1; T(2,1)=1; double th=(90./180.)*PI;\n'
+                       '  T2(0,0)=cos(th); T2(0,2)=sin(th); T2(1,1)=1; T2(2,0)=-sin(th); T2(2,2)=cos(th);\n'
+                       '  Bezier3Obj o(Vec3(1,2,3), 2.0, a[1], Color(1,1,1), Material(Color(.5,.5,.5), Color(0,0,0), Color(0,0,0)), T2*T);\n'
+                       '  for (size_t i = 0; i < o.patch_count(); i++) for (int k = 0; k < 16; k++)\n'
+                       '    printf("%.17g %.17g %.17g\\n", o.patch(i).P[k].val[0], o.patch(i).P[k].val[1], o.patch(i).P[k].val[2]);\n}\n')
+        exe = tmp_path / "dump"
+        subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include", "raytrace3"), "-I", os.path.join(root, "include"),
+                        str(src), "-o", str(exe)], check=True)
+        out = subprocess.run([str(exe), str(path)], check=True, capture_output=True, text=True).stdout
+        got = np.array([[float(x) for x in line.split()] for line in out.strip().splitlines()]).reshape(-1, 16, 3)
+        assert got.shape == patches.shape and np.allclose(got, patches, rtol=0, atol=1e-12)
+    with open(path, "w") as f:
+        f.write("1\n4 3\n" + "0 0 0\n" * 20)
+    with pytest.raises(ValueError, match="degree 4 x 3"):
+        scenes.load_bpt(str(path))
