@@ -67,7 +67,7 @@ struct SceneView {
     const DevObject* objs;      // LDS
     const double* patch_box;    // LDS, n_patches x 6 (pmin, pmax)
     const float* patch_cp;      // LDS, n_patches x 48
-    // Newton tables in GLOBAL memory (wave-uniform reads of them become scalar loads): per patch the 48
+    // Newton tables in GLOBAL memory (read at wave-uniform addresses): per patch the 48
     // power-basis coefficients of S(u,v) - centre, and the centre (see newton_coop)
     const float* pw_q;
     const double* pw_c;
@@ -398,8 +398,10 @@ __device__ __forceinline__ void newton_restart(const float* Q, f3 o, f3 d, float
 // restarts, ties to the lowest restart (the reference keeps the first pushed
 // minimum).  so, sd (the ray, fp64), sub (the ray's NEWTON hash state) and patch are wave-uniform.
 // Returns a wave-uniform (t,u,v); t = 1e20 when nothing converged.
-// pw_q / pw_c are GLOBAL memory: with a wave-uniform patch index the reads are scalar loads and
-// the 48 coefficients live in SGPRs for the whole solve (no vector registers spent on them).
+// pw_q / pw_c are GLOBAL memory, read at a wave-uniform address: in k_newton the compiler turns the reads into scalar
+// loads and the 48 coefficients live in SGPRs; in k_trace, which stores to global memory between solves, it reads them
+// with vector loads of one address (a broadcast) into 48 VGPRs.  Forcing scalar loads there (constant address space)
+// was measured slower: the scalar registers they take are spilled elsewhere in the loop.
 __device__ __forceinline__ void newton_coop(const float* __restrict__ pw_q, const double* __restrict__ pw_c, int patch, d3 so, d3 sd,
                                             uint32_t sub, float& rt, float& ru, float& rv) {
     const int lane = lane_id();
