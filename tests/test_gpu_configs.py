@@ -545,4 +545,4 @@ def test_contexts_and_films_release_their_memory():
         cycle()
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
-    assert free0 - free1 < 64 << 20, (free0, free1)
+    assert free0 - free1 < 256 << 20, (free0, free1)      # one cycle holds about 2 GB
