@@ -164,10 +164,11 @@ const char* sppm_last_error(const sppm_ctx* ctx);
 /* Upload the flattened scene.  Replaces Scene::init's object graph as seen by
  * Scene::NearCollide (raytracer/Scene.h:165-182); patch and object AABBs are
  * rebuilt as Bezier3::read / Bezier3Obj do (raytracer/Bezier.h:167-175, :226-231).
- * Waits for the passes still queued on the context.  Capacity (SPPM_E_CAPACITY
- * beyond it): 256 objects, 256 Bezier patches, and 224 B per object + 244 B per
- * patch within the 64 KiB the kernels stage in LDS (the reference's scene: 9
- * objects, 32 patches); 2^30 texels. */
+ * Waits for the passes still queued on the context.  Scene tables of up to
+ * 64 KiB (224 B per object + 244 B per Bezier patch; the reference's scene: 9
+ * objects, 32 patches, 10 KiB) are staged in LDS by the kernels, larger ones are
+ * read from global memory.  Capacity (SPPM_E_CAPACITY beyond it): 4096 objects,
+ * 65536 patches, 2^30 texels. */
 int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* scene);
 
 /* Pass 1: RayTracer::GetHitPoint + ViewTrace (raytracer/Raytracer.h:102-116,

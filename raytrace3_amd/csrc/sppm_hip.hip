@@ -95,13 +95,20 @@ __device__ __forceinline__ uint32_t key_bucket(uint64_t key, uint32_t mask) {
 
 // ------------------------------------------------------------------ LDS scene staging
 extern __shared__ double lds_scene[];
+// Scene tables of up to SCENE_LDS_MAX bytes are copied to LDS by every workgroup (IN_LDS); larger ones (hundreds of
+// Bezier patches) are read where they lie in global memory, through the same SceneView.
+#define SCENE_LDS_MAX (64 * 1024)
+template <bool IN_LDS>
 __device__ __forceinline__ SceneView stage_scene(const SceneParams& sp) {
-    const uint32_t* src = (const uint32_t*)sp.blob;
-    uint32_t* dst = (uint32_t*)lds_scene;
-    for (int i = threadIdx.x; i < sp.blob_bytes / 4; i += blockDim.x) dst[i] = src[i];
-    __syncthreads();
+    const char* base = sp.blob;
+    if (IN_LDS) {
+        const uint32_t* src = (const uint32_t*)sp.blob;
+        uint32_t* dst = (uint32_t*)lds_scene;
+        for (int i = threadIdx.x; i < sp.blob_bytes / 4; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+        base = (const char*)lds_scene;
+    }
     SceneView S;
-    const char* base = (const char*)lds_scene;
     S.objs = (const DevObject*)base;
     S.patch_box = (const double*)(base + sp.off_box);
     S.patch_cp = (const float*)(base + sp.off_cp);
@@ -243,13 +250,13 @@ struct TraceParams {
 // box culls leave patches to solve is PARKED: its state and one task per patch go to queues,
 // k_newton solves all tasks of the round at full occupancy, and the next launch resumes the ray
 // from its record.  This keeps the 50 x 10 Newton iterations out of the divergent path loop.
-template <int MODE, bool COOP>
+template <int MODE, bool COOP, bool IN_LDS>
 __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC : TRACE_COOP_OCC) : 3) k_trace(SceneParams sp, TraceParams tp) {
     const unsigned long long n_resume = tp.resume ? min(*tp.n_resume_dev, tp.park_cap) : 0ull;   // records beyond the capacity were never written
     const unsigned long long total = n_resume + tp.fresh_count;
     // the host sizes a resume launch without knowing its count: workgroups beyond the work leave at once
     if (blockIdx.x > 0 && (unsigned long long)blockIdx.x * blockDim.x >= total) return;
-    SceneView S = stage_scene(sp);
+    SceneView S = stage_scene<IN_LDS>(sp);
     const int lane = lane_id();
     bool active = false, pending = false, exhausted = (total == 0);
     d3 o = mk(0, 0, 0), d = mk(0, 0, 1);
@@ -264,7 +271,7 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
     unsigned long long work_next = 0, work_end = 0;     // this wave's claimed work items, wave-uniform
     unsigned long long chunk_base = 0;                  // first item of the chunk the emission directions in LDS belong to
     // per-wave LDS slice behind the scene tables: emission directions of the claimed photon chunk
-    double* emit_dir = (double*)((char*)lds_scene + ((sp.blob_bytes + 15) & ~15)) + (threadIdx.x >> 6) * (3 * 128);
+    double* emit_dir = (double*)((char*)lds_scene + (IN_LDS ? ((sp.blob_bytes + 15) & ~15) : 0)) + (threadIdx.x >> 6) * (3 * 128);
     unsigned long long slot_next = 0, slot_end = 0;     // this wave's open chunk of output slots (deposits / raw HitPoints), wave-uniform
     const uint32_t wave_slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     slot_next = tp.wave_chunks[2 * wave_slot];
@@ -1173,9 +1180,10 @@ __global__ void k_zero3(uint32_t* p0, size_t n0, uint32_t* p1, size_t n1, uint32
 }
 
 // ------------------------------------------------------------------ parity hooks
+template <bool IN_LDS>
 __global__ void __launch_bounds__(256) k_debug_near_collide(SceneParams sp, uint32_t n, const double* org, const double* dir, uint32_t rng,
                                                             sppm_collision* out, DevCounters* counters) {
-    SceneView S = stage_scene(sp);
+    SceneView S = stage_scene<IN_LDS>(sp);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < n;
     d3 o = active ? ld3(org + 3 * (size_t)i) : mk(0, 0, 0), d = active ? ld3(dir + 3 * (size_t)i) : mk(0, 0, 1);
@@ -1197,7 +1205,7 @@ __global__ void __launch_bounds__(256) k_debug_near_collide(SceneParams sp, uint
 
 __global__ void __launch_bounds__(256) k_debug_newton(SceneParams sp, uint32_t n, const double* org, const double* dir, const int* patch,
                                                       uint32_t rng, double* out_tuv) {
-    SceneView S = stage_scene(sp);
+    SceneView S = stage_scene<false>(sp);   // only the Newton tables are used, and those are in global memory anyway
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < n;
     const int lane = lane_id();
@@ -1259,6 +1267,8 @@ struct sppm_ctx {
     // scene
     bool have_scene = false;
     DevBuf<char> blob; int blob_bytes = 0, off_box = 0, off_cp = 0, off_pobj = 0, n_objs = 0, n_patches = 0;
+    bool scene_in_lds = true;             // the scene tables fit the LDS staging area (else: read from global memory)
+    bool coop_only = false;               // more patches than a parked ray's patch mask can name: rays are never parked
     DevBuf<uchar4> texels;
     DevBuf<float> pw_q; DevBuf<double> pw_c;   // Newton tables (power basis around the patch centres)
     DevBuf<DevLight> lights; int n_lights = 0;
@@ -1461,8 +1471,8 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
     if (s->n_lights <= 0 || !s->lights) return fail(ctx, SPPM_E_INVALID, "scene has no lights");
     if (s->n_patches < 0 || (s->n_patches > 0 && !s->patches)) return fail(ctx, SPPM_E_INVALID, "bad patch array");
     if (s->n_textures < 0 || (s->n_textures > 0 && !s->textures)) return fail(ctx, SPPM_E_INVALID, "bad texture array");
-    if (s->n_patches > 64 * SPPM_MASK_WORDS) return fail(ctx, SPPM_E_CAPACITY, "more than 256 Bezier patches in one scene");
-    if (s->n_objects > 256) return fail(ctx, SPPM_E_CAPACITY, "more than 256 objects in one scene");
+    if (s->n_patches > (1 << 16)) return fail(ctx, SPPM_E_CAPACITY, "more than 65536 Bezier patches in one scene");
+    if (s->n_objects > (1 << 12)) return fail(ctx, SPPM_E_CAPACITY, "more than 4096 objects in one scene");
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));   // passes still queued read the tables replaced below
     const int no = s->n_objects, np = s->n_patches;
@@ -1470,7 +1480,6 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
     const int off_cp = off_box + np * 6 * (int)sizeof(double);
     const int off_pobj = off_cp + np * 48 * (int)sizeof(float);
     const int bytes = (off_pobj + np * (int)sizeof(int) + 15) & ~15;
-    if (bytes > 64 * 1024) return fail(ctx, SPPM_E_CAPACITY, "scene tables exceed the 64 KiB LDS staging area (too many patches/objects)");
     std::vector<char> blob((size_t)bytes, 0);
     DevObject* objs = (DevObject*)blob.data();
     double* box = (double*)(blob.data() + off_box);
@@ -1563,6 +1572,10 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
     HIPCHK(ctx->blob.reserve((size_t)bytes));
     HIPCHK(hipMemcpy(ctx->blob.p, blob.data(), (size_t)bytes, hipMemcpyHostToDevice));
     ctx->blob_bytes = bytes; ctx->off_box = off_box; ctx->off_cp = off_cp; ctx->off_pobj = off_pobj; ctx->n_objs = no; ctx->n_patches = np;
+    // Large scenes: tables beyond the LDS staging area are read from global memory, and with more patches than the patch
+    // mask of a parked ray holds every Bezier solve happens in the tracing wave (the default anyway).
+    ctx->scene_in_lds = bytes <= SCENE_LDS_MAX;
+    ctx->coop_only = np > 64 * SPPM_MASK_WORDS || !ctx->scene_in_lds;
     std::vector<uchar4> tx(std::max<size_t>(1, total));
     for (int t = 0; t < s->n_textures; t++) {
         const uint8_t* src = s->textures[t].texels;
@@ -1660,9 +1673,10 @@ static int close_chunks(sppm_ctx* ctx, Deposit* dep, RawHit* hits, uint64_t cap)
 template <int MODE>
 static void launch_trace(sppm_ctx* ctx, bool coop, int blocks, const SceneParams& sp, const TraceParams& tp) {
     // dynamic LDS: the scene tables, then (photon pass) 4 waves x 128 emission directions
-    const size_t lds = (((size_t)ctx->blob_bytes + 15) & ~(size_t)15) + (MODE == MODE_PHOTON ? 4 * 128 * 3 * sizeof(double) : 0);
-    if (coop) hipLaunchKernelGGL((k_trace<MODE, true>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
-    else hipLaunchKernelGGL((k_trace<MODE, false>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
+    const size_t lds = (ctx->scene_in_lds ? (((size_t)ctx->blob_bytes + 15) & ~(size_t)15) : 0) + (MODE == MODE_PHOTON ? 4 * 128 * 3 * sizeof(double) : 0);
+    if (!ctx->scene_in_lds) hipLaunchKernelGGL((k_trace<MODE, true, false>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);   // coop_only
+    else if (coop) hipLaunchKernelGGL((k_trace<MODE, true, true>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
+    else hipLaunchKernelGGL((k_trace<MODE, false, true>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
 }
 static int launch_trace_mode(sppm_ctx* ctx, int mode, bool coop, int blocks, const TraceParams& tp) {
     const SceneParams sp = ctx->scene_params();
@@ -1762,7 +1776,7 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
     // extra launches of a park round.  With pixels in row order the rays that meet the object are whole
     // waves, which would serialise 64 solves each while the other waves idle: then they are parked and
     // solved by k_newton (SPPM_EYE_SCATTER=0, or SPPM_PHOTON_COOP=0 for photons).
-    const bool first_coop = ctx->force_coop || (mode == MODE_PHOTON && ctx->photon_coop) || (mode == MODE_EYE && ctx->eye_scatter);
+    const bool first_coop = ctx->force_coop || ctx->coop_only || (mode == MODE_PHOTON && ctx->photon_coop) || (mode == MODE_EYE && ctx->eye_scatter);
     const bool legacy = (mode == MODE_PHOTON && !first_coop);   // photons with parked solves: every round looks at the counters
     if (int rc = set_round(0, true)) return rc;
     int first_blocks = blocks_for(fresh_count, first_coop);
@@ -1792,7 +1806,7 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
         HIPCHK(hipMemsetAsync(park_ctr(nxt), 0, sizeof(unsigned long long), ctx->stream));
         HIPCHK(hipMemsetAsync(task_ctr(nxt), 0, sizeof(unsigned long long), ctx->stream));
         if (int rc = set_round(cur, false)) return rc;
-        const bool coop = !legacy || ctx->force_coop || n_park < ctx->coop_threshold;
+        const bool coop = !legacy || ctx->force_coop || ctx->coop_only || n_park < ctx->coop_threshold;
         if (int rc = launch_trace_mode(ctx, mode, coop, blocks_for(n_park, coop), tp)) return rc;
         cur = nxt;
     }
@@ -2173,8 +2187,12 @@ int sppm_debug_near_collide(sppm_ctx* ctx, uint64_t n, const double* org, const 
         if (o.reserve(3 * n) != hipSuccess || d.reserve(3 * n) != hipSuccess || c.reserve(n) != hipSuccess) { rc = fail(ctx, SPPM_E_NOMEM, "hipMalloc failed"); break; }
         (void)hipMemcpy(o.p, org, 3 * n * sizeof(double), hipMemcpyHostToDevice);
         (void)hipMemcpy(d.p, dir, 3 * n * sizeof(double), hipMemcpyHostToDevice);
-        hipLaunchKernelGGL(k_debug_near_collide, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)ctx->blob_bytes, ctx->stream,
-                           ctx->scene_params(), (uint32_t)n, o.p, d.p, host_rng_base(seed, replica * 4u + D_EYE), c.p, ctx->counters.p);
+        if (ctx->scene_in_lds)
+            hipLaunchKernelGGL(k_debug_near_collide<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)ctx->blob_bytes, ctx->stream,
+                               ctx->scene_params(), (uint32_t)n, o.p, d.p, host_rng_base(seed, replica * 4u + D_EYE), c.p, ctx->counters.p);
+        else
+            hipLaunchKernelGGL(k_debug_near_collide<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->scene_params(), (uint32_t)n, o.p, d.p, host_rng_base(seed, replica * 4u + D_EYE), c.p, ctx->counters.p);
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { rc = fail(ctx, SPPM_E_DEVICE, hipGetErrorString(e)); break; }
         (void)hipMemcpy(out, c.p, n * sizeof(sppm_collision), hipMemcpyDeviceToHost);
@@ -2263,7 +2281,7 @@ int sppm_debug_newton(sppm_ctx* ctx, uint64_t n, const double* org, const double
         (void)hipMemcpy(o.p, org, 3 * n * sizeof(double), hipMemcpyHostToDevice);
         (void)hipMemcpy(d.p, dir, 3 * n * sizeof(double), hipMemcpyHostToDevice);
         (void)hipMemcpy(p.p, patch, n * sizeof(int), hipMemcpyHostToDevice);
-        hipLaunchKernelGGL(k_debug_newton, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)ctx->blob_bytes, ctx->stream,
+        hipLaunchKernelGGL(k_debug_newton, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                            ctx->scene_params(), (uint32_t)n, o.p, d.p, p.p, host_rng_base(seed, replica * 4u + D_EYE), r.p);
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { rc = fail(ctx, SPPM_E_DEVICE, hipGetErrorString(e)); break; }
