@@ -803,9 +803,9 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_reduce_close(const uint32
 // of 64 deposits (contiguous after the sort: one coalesced 32 B + 32 B load per lane) and
 // GATHER_ROWS rows at a time are held in registers while every HitPoint of the cell is broadcast
 // across the wave and tested against them.  Per (HitPoint, pass) the accepted flux is summed over
-// the lanes with DPP adds, the counts with ballots; the owner lane keeps the running sums and
-// writes its HitPoint once: no atomics on HitPoints, and a deposit is fetched once per cell
-// instead of once per HitPoint.
+// the 16 lanes of each DPP row, the counts with ballots; one lane per row keeps that row's running
+// sums of the HitPoint, the four meet when the tile is done and the owner lane writes its HitPoint
+// once: no atomics on HitPoints, and a deposit is fetched once per cell instead of once per HitPoint.
 #ifndef GATHER_ROWS
 #define GATHER_ROWS 6
 #endif
@@ -813,15 +813,13 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_reduce_close(const uint32
 #define GATHER_TILE 16u      // HitPoints per tile (<= 64: one accumulator lane each)
 #endif
 
-// Sum over the 64 lanes, returned wave-uniform.
-__device__ __forceinline__ float wave_total_f(float v) {
+// Sum over the 16 lanes of each DPP row, left in every lane of the row.
+__device__ __forceinline__ float row_total_f(float v) {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));   // row_mirror: every lane = its row's sum
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1, 3
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2, 3
-    return bcast_f(v, 63);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));   // row_mirror
+    return v;
 }
 
 // One tile = GATHER_TILE consecutive grid-sorted HitPoints, one per lane of the first GATHER_TILE lanes.
@@ -857,8 +855,14 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
     const float4 mnr = hp_nr[valid ? mine : base];
     const double mr2 = FIXED_R2 ? SPPM_INIT_R2 : hp_r2[valid ? mine : base];
     const float4 mw = hp_wgt[valid ? mine : base];
+    // Running sums of HitPoint j: its flux in lanes j, 16 + j, 32 + j, 48 + j, one partial sum per DPP row (j < GATHER_TILE <= 16),
+    // so that a sweep only reduces inside the rows of 16 lanes (four DPP adds per channel instead of a whole-wave reduction
+    // and a broadcast); the four partial sums meet once, when the tile is done.  The count, which comes from ballots, is kept
+    // in all four lanes alike.
+    static_assert(GATHER_TILE <= 16, "one accumulator lane per DPP row and HitPoint");
     float tr = 0, tg = 0, tb = 0;
     uint32_t tn = 0;
+    const int lane15 = lane & 15;
     uint64_t todo = __ballot(valid);
     if (PIECE) todo &= 1ull << (piece.lead & 63u);               // only the cell the piece belongs to
     while (todo) {
@@ -962,8 +966,8 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
                     }
                 }
                 if (pn) {
-                    pr = wave_total_f(pr); pg = wave_total_f(pg); pb = wave_total_f(pb);
-                    if (lane == j) { tr += pr; tg += pg; tb += pb; tn += pn; }
+                    pr = row_total_f(pr); pg = row_total_f(pg); pb = row_total_f(pb);
+                    if (lane15 == j) { tr += pr; tg += pg; tb += pb; tn += pn; }
                     acc_n += pn;
                 }
             }
@@ -988,6 +992,8 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
             }
         }
     }
+    tr += __shfl_xor(tr, 16, 64); tg += __shfl_xor(tg, 16, 64); tb += __shfl_xor(tb, 16, 64);
+    tr += __shfl_xor(tr, 32, 64); tg += __shfl_xor(tg, 32, 64); tb += __shfl_xor(tb, 32, 64);
     if (valid && tn) {
         if (PIECE) {
             float* t = (float*)&hp_tao[mine];
