@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — SPPM hot path on MI355X: Mphotons/s and ms per SPPM iteration.
 
-Two replica iterations are in flight per GPU by default (`--inflight 2`: two library contexts =
-two HIP streams, used alternately), the way the reference keeps four replicas in flight with its
-OpenMP loop (Raytracer.h:442): the latency-bound eye pass of one iteration overlaps the photon pass
-of the other.  `--inflight 1` runs them strictly one after the other (per-kernel HIP-event
-durations are then undisturbed by the neighbour stream).
+Three replica iterations are in flight per GPU by default (`--inflight 3`: three library contexts =
+three HIP streams, used in turn), the way the reference keeps four replicas in flight with its
+OpenMP loop (Raytracer.h:442): contexts that share a GPU launch persistent grids small enough for the
+trace of one iteration, the gather of another and the eye pass of the third to be resident on the CUs
+together.  `--inflight 1` runs the iterations strictly one after the other, on full grids (per-kernel
+HIP-event durations are then undisturbed by the neighbour streams).
 
 One step = one SPPM iteration of one replica on the teapot Cornell scene at 800x600
 (eye pass + HitPoint grid + photon pass + resolve, plus the all-reduce of the flux image
@@ -85,16 +86,24 @@ def _kernel(d, name):
     return {}
 
 
-def measured_valu():
+def _profiles(shared):
+    """The committed PMC summaries, oldest first, of the launch mode asked for: several iterations in flight (the
+    default command; its persistent grids are sized to share the GPU) or one."""
+    import glob
+    want = "default" if shared else "single"
+    return [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))) if want in os.path.basename(f)]
+
+
+def measured_valu(shared):
     """Vector instructions per launch of the two dominant kernels from the committed PMC profile
     (SQ_INSTS_VALU, wave instructions): both kernels live on VALU issue, not on HBM."""
-    import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+    for f in _profiles(shared):
         try:
             with open(f) as fh:
                 d = json.load(fh)
-            g, t = _kernel(d, "k_gather").get("SQ_INSTS_VALU"), d.get("k_trace<1, true>", {}).get("SQ_INSTS_VALU")
+            tk = [v for k, v in d.items() if k.startswith("k_trace<1, true")]      # the photon pass with in-wave solves
+            g, t = _kernel(d, "k_gather").get("SQ_INSTS_VALU"), (tk[0].get("SQ_INSTS_VALU") if tk else None)
             if g and t:
                 g += _kernel(d, "k_gather_split").get("SQ_INSTS_VALU") or 0.0
                 best = {"k_gather_wave_insts": float(g), "k_trace_photon_wave_insts": float(t), "source": "profiles/" + os.path.basename(f)}
@@ -103,13 +112,12 @@ def measured_valu():
     return best
 
 
-def measured_traffic():
+def measured_traffic(shared):
     """HBM bytes per gather (k_gather and k_gather_split) from the rocprofv3 PMC passes committed under profiles/
     ((2 * FETCH_SIZE + WRITE_SIZE) * 1024, collected by tools/gpu_profile.sh on this same command);
     None when no such profile is in the tree."""
-    import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+    for f in _profiles(shared):
         try:
             with open(f) as fh:
                 d = json.load(fh)
@@ -125,13 +133,13 @@ def measured_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2_teapot_800x600")
     ap.add_argument("--rounds", type=int, default=0, help="rounds per GPU per step (default: the config's)")
     ap.add_argument("--cpu-rounds", type=int, default=4000, help="photon rounds (x100 photons) per CPU replica: ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("SPPM_INFLIGHT", "2")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("SPPM_INFLIGHT", "3")),
                     help="replica iterations in flight per GPU (one context = one HIP stream each)")
     args = ap.parse_args()
 
@@ -229,7 +237,7 @@ def main():
         photons_total = per_rank * world * args.steps
         # the committed rocprofv3 counters are of the default workload: they say nothing about another configuration
         profiled = args.config == "c2_teapot_800x600" and rounds == cfg_rounds
-        traffic = measured_traffic() if profiled else None
+        traffic = measured_traffic(len(ctxs) > 1) if profiled else None
         gather_s = alone["gather_ms"] * alone_steps / 1e3
         achieved = bytes_model / gather_s / 1e9 if gather_s > 0 else 0.0
         pass_s = (alone["photon_trace_ms"] + alone["deposit_sort_ms"] + alone["gather_ms"]) / 1e3    # one photon pass, undisturbed
@@ -254,10 +262,11 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_model / max(1, gather_launches),
                          "avg_launch_ms": alone["gather_ms"] * alone_steps / max(1, gather_launches),
                          "measured": "HIP events on the library's stream" + (f", {ALONE_STEPS} iterations with one iteration in flight after the "
-                                     "timed region (spans of the timed region include the other stream's kernels)" if len(ctxs) > 1 else
+                                     "timed region (spans of the timed region include the other streams' kernels), launched as in the "
+                                     "timed region: persistent grids sized to share the GPU with the other contexts' kernels" if len(ctxs) > 1 else
                                      ", over the timed region")},
         }
-        valu = measured_valu() if profiled else None
+        valu = measured_valu(len(ctxs) > 1) if profiled else None
         if valu:
             gl = max(1, gather_launches)
             valu["k_gather_frac_of_valu_peak"] = valu["k_gather_wave_insts"] * 64 / (alone["gather_ms"] * alone_steps / gl / 1e3) / VALU_PEAK_LANE_OPS

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -807,7 +808,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_reduce_close(const uint32
 // sums of the HitPoint, the four meet when the tile is done and the owner lane writes its HitPoint
 // once: no atomics on HitPoints, and a deposit is fetched once per cell instead of once per HitPoint.
 #ifndef GATHER_ROWS
-#define GATHER_ROWS 6
+#define GATHER_ROWS 3        // 78 VGPRs: three gather workgroups and one trace workgroup fit a CU's register files together
 #endif
 #ifndef GATHER_TILE
 #define GATHER_TILE 16u      // HitPoints per tile (<= 64: one accumulator lane each)
@@ -1264,6 +1265,10 @@ uint32_t next_pow2(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p
 
 }  // namespace
 
+// contexts alive per GPU of this process (see sppm_ctx::trace_blocks_per_cu)
+static std::atomic<int> g_live_contexts[64];
+static bool shares_gpu(int device) { return device >= 0 && device < 64 && g_live_contexts[device].load(std::memory_order_relaxed) > 1; }
+
 #define CTL_SCALARS 16
 struct sppm_ctx {
     int device = 0;
@@ -1288,9 +1293,13 @@ struct sppm_ctx {
     bool photon_coop = true;
     bool eye_scatter = true;              // eye work items visit the pixels in a scattered order (TraceParams::pix_mul)
     int newton_blocks_per_cu = 8;
-    int gather_blocks_per_cu = 4;
-    int trace_blocks_per_cu = 0;          // 0: as many trace workgroups per CU as stay resident (2 or 3)
-    int eye_blocks_per_cu = 0;            // 0: as many trace workgroups as the pixels allow (up to 4 per CU)
+    // Persistent grids, in workgroups per CU; 0 = chosen at every launch: a context that is alone on its GPU fills the
+    // CUs (trace 2 per CU, gather 5), contexts that share a GPU (several iterations in flight) leave each other room: one
+    // trace workgroup (<= 256 VGPRs per lane) and three gather workgroups (78) fit the register file of every SIMD
+    // together, and a trace kernel of one context then runs beside the gather of another instead of after it.
+    int gather_blocks_per_cu = 0;
+    int trace_blocks_per_cu = 0;
+    int eye_blocks_per_cu = 0;            // the eye pass's own value of trace_blocks_per_cu (0: the same rule)
     int scatter_blocks_per_cu = 32;
     bool verbose = false;
     DevBuf<uint32_t> hstart;
@@ -1428,7 +1437,7 @@ int sppm_create(sppm_ctx** out, int device_id) {
     if (const char* b = getenv("SPPM_FORCE_COOP")) ctx->force_coop = atoi(b) != 0;
     if (const char* b = getenv("SPPM_EYE_SCATTER")) ctx->eye_scatter = atoi(b) != 0;
     if (const char* b = getenv("SPPM_PHOTON_COOP")) ctx->photon_coop = atoi(b) != 0;
-    if (const char* b = getenv("SPPM_GATHER_BPC")) ctx->gather_blocks_per_cu = std::max(1, atoi(b));
+    if (const char* b = getenv("SPPM_GATHER_BPC")) ctx->gather_blocks_per_cu = std::max(0, atoi(b));
     if (const char* b = getenv("SPPM_SCATTER_BPC")) ctx->scatter_blocks_per_cu = std::max(1, atoi(b));
     if (const char* b = getenv("SPPM_TRACE_BPC")) ctx->trace_blocks_per_cu = std::max(0, atoi(b));
     if (const char* b = getenv("SPPM_EYE_BPC")) ctx->eye_blocks_per_cu = std::max(0, atoi(b));
@@ -1444,6 +1453,7 @@ int sppm_create(sppm_ctx** out, int device_id) {
     }
     (void)hipMemset(ctx->ctl.p, 0, ctx->ctl_words() * sizeof(unsigned long long));
     (void)hipMemset(ctx->counters.p, 0, sizeof(DevCounters));
+    if (device_id < 64) g_live_contexts[device_id].fetch_add(1);
     *out = ctx;
     return SPPM_OK;
 }
@@ -1464,6 +1474,7 @@ void sppm_destroy(sppm_ctx* ctx) {
     if (ctx->host_q) (void)hipHostFree(ctx->host_q);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->device < 64) g_live_contexts[ctx->device].fetch_sub(1);
     delete ctx;
 }
 
@@ -1748,7 +1759,10 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
     const int max_blocks = trace_max_blocks(ctx);
     // persistent workgroups: as many as stay resident (2 per CU with in-wave solves, 3 without), not more
     auto blocks_for = [&](uint64_t items, bool coop) {
-        const int per_cu = ctx->trace_blocks_per_cu > 0 ? ctx->trace_blocks_per_cu : (coop ? (mode == MODE_EYE ? TRACE_EYE_OCC : TRACE_COOP_OCC) : 3);
+        const int per_cu = (mode == MODE_EYE && ctx->eye_blocks_per_cu > 0) ? ctx->eye_blocks_per_cu
+                           : ctx->trace_blocks_per_cu > 0 ? ctx->trace_blocks_per_cu
+                           : shares_gpu(ctx->device)    ? 1
+                                                        : (coop ? (mode == MODE_EYE ? TRACE_EYE_OCC : TRACE_COOP_OCC) : 3);
         const uint64_t cap = std::min<uint64_t>((uint64_t)max_blocks, (uint64_t)ctx->num_cu * per_cu);
         return (int)std::max<uint64_t>(1, std::min<uint64_t>(cap, (items + 255) / 256));
     };
@@ -1786,7 +1800,6 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
     const bool legacy = (mode == MODE_PHOTON && !first_coop);   // photons with parked solves: every round looks at the counters
     if (int rc = set_round(0, true)) return rc;
     int first_blocks = blocks_for(fresh_count, first_coop);
-    if (mode == MODE_EYE && ctx->eye_blocks_per_cu > 0) first_blocks = std::min(first_blocks, ctx->num_cu * ctx->eye_blocks_per_cu);
     if (int rc = launch_trace_mode(ctx, mode, first_coop, first_blocks, tp)) return rc;
     int cur = 0;   // queue written by the last launch
     if (!legacy) {
@@ -2022,7 +2035,8 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
         if (ctx->n_hp > 0) {
             tic(ctx, PH_GATHER);
             const uint64_t tiles = (ctx->n_hp + GATHER_TILE - 1) / GATHER_TILE;
-            const int blocks = (int)std::max<uint64_t>(8, std::min<uint64_t>((uint64_t)ctx->num_cu * ctx->gather_blocks_per_cu, ((tiles + 3) / 4 + 7) / 8 * 8));
+            const int gather_bpc = ctx->gather_blocks_per_cu > 0 ? ctx->gather_blocks_per_cu : (shares_gpu(ctx->device) ? 3 : 5);
+            const int blocks = (int)std::max<uint64_t>(8, std::min<uint64_t>((uint64_t)ctx->num_cu * gather_bpc, ((tiles + 3) / 4 + 7) / 8 * 8));
             const uint32_t piece_cap = 1u << 20;
             HIPCHK(ctx->pieces.reserve(piece_cap));
             // the deposits that found their bucket full (normally a handful) ride along with the pieces
