@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — SPPM hot path on MI355X: Mphotons/s and ms per SPPM iteration.
 
-Three replica iterations are in flight per GPU by default (`--inflight 3`: three library contexts =
-three HIP streams, used in turn), the way the reference keeps four replicas in flight with its
+Five replica iterations are in flight per GPU by default (`--inflight 5`: five library contexts =
+five HIP streams, used in turn), the way the reference keeps four replicas in flight with its
 OpenMP loop (Raytracer.h:442): contexts that share a GPU launch persistent grids small enough for the
-trace of one iteration, the gather of another and the eye pass of the third to be resident on the CUs
-together.  `--inflight 1` runs the iterations strictly one after the other, on full grids (per-kernel
+trace of one iteration, the gather of another and the eye pass / grid build / resolve of others to be
+resident on the CUs together.  `--inflight 1` runs the iterations strictly one after the other, on full grids (per-kernel
 HIP-event durations are then undisturbed by the neighbour streams).
 
 One step = one SPPM iteration of one replica on the teapot Cornell scene at 800x600
@@ -29,6 +29,13 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# One hardware queue per context: with HIP's default of 4 queues per process the streams of five contexts (and torch's
+# own) are folded onto four queues, and kernels of contexts that share a queue run one after the other.  Read by the HIP
+# runtime when it starts, hence set before anything touches the GPU.
+# (The GPU boxes of this pool export the default, 4, explicitly, so the value is set here, not merely defaulted;
+# SPPM_HW_QUEUES=0 leaves the environment as it is.)
+if os.environ.get("SPPM_HW_QUEUES", "8") != "0":
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("SPPM_HW_QUEUES", "8")
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (spec)
@@ -133,13 +140,13 @@ def measured_traffic(shared):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c2_teapot_800x600")
     ap.add_argument("--rounds", type=int, default=0, help="rounds per GPU per step (default: the config's)")
     ap.add_argument("--cpu-rounds", type=int, default=4000, help="photon rounds (x100 photons) per CPU replica: ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("SPPM_INFLIGHT", "3")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("SPPM_INFLIGHT", "5")),
                     help="replica iterations in flight per GPU (one context = one HIP stream each)")
     args = ap.parse_args()
 

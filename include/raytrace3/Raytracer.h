@@ -9,9 +9,9 @@
 //   SPPM_ONETIME  photons per round and light           (100,   Raytracer.h:218)
 //   SPPM_ITERS    outer SPPM iterations                 (100000, Raytracer.h:425)
 //   SPPM_SEED     seed of the counter-based streams     (20260101)
-//   SPPM_DEVICES  comma-separated GPU ids, one library context (= HIP stream) per entry; the four
-//                 replicas of an iteration are dealt over them.  Default "0,0": two contexts on GPU 0,
-//                 so the eye pass of one replica overlaps the photon pass of another.
+//   SPPM_DEVICES  comma-separated GPU ids, one library context (= HIP stream) per entry; the replicas go
+//                 round them.  Default "0,0,0,0": four contexts on GPU 0, whose kernels share the CUs (the trace
+//                 of one replica beside the gather of another).  Two GPUs: "0,1,0,1,0,1,0,1".
 //   SPPM_INITIAL_N / SPPM_UPDATE_ROUNDS   HitPoints start with this N (0: the reference, whose update() then never runs) and,
 //                 if positive, update() runs after every SPPM_UPDATE_ROUNDS rounds (1) — sppm_set_radius_update
 //   SPPM_SAVE_EVERY        write the running mean every n-th outer iteration (1, as the reference) and after the last
@@ -24,6 +24,7 @@
 #include <cstring>
 #include <iostream>
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -260,7 +261,12 @@ class SPPMRayTracer {
 public:
     // The outer SPPM loop (Raytracer.h:421-477): per iteration four replicas with the camera moved by
     // 0.00015 * a random unit vector, their images summed, the running mean tone-mapped and written out
-    // (aaanew<i/10>.ppm).  Replicas are spread over SPPM_DEVICES; the sum stays on the GPUs.
+    // (aaanew<i/10>.ppm).  The reference runs the four replicas on four OpenMP threads.  Here a pass is queued on a
+    // GPU stream and the host does not wait for it, so one host thread hands the replicas to the library contexts
+    // (SPPM_DEVICES) in turn: while it waits for the HitPoints of one context's eye pass, the photon passes queued on
+    // the other contexts run.  Going round the contexts in a fixed order also keeps their passes a third of an
+    // iteration apart, which is what lets the trace of one and the gather of another share the CUs (threads racing to
+    // submit were measured 10 % slower).  The image sum stays on the GPUs (one film per GPU).
     void render(Scene scene, Camera camera) {
         const long long sppmtime = sppm_host::env_ll("SPPM_ITERS", 100000);
         const long long save_every = std::max(1LL, sppm_host::env_ll("SPPM_SAVE_EVERY", 1));
@@ -275,41 +281,39 @@ public:
             first = sppm_host::load_checkpoint(resume, films, devices[0]);
             std::cerr << "resume:" << resume << " at iteration " << first << std::endl;
         }
-        Camera c[4];
+        std::vector<Camera> cams(devices.size(), camera);   // one per context, assigned to again and again (their images are allocated once)
         for (long long i = first; i < sppmtime; i++) {
-            RayTracer rt[4];
-            sppm_film* film[4];
             for (int k = 0; k < 4; k++) {
-                c[k] = camera;
-                c[k].MoveTo(camera.pos + 0.00015 * Vec3::GetUnitRandVec());
-                c[k].lookAt(camera.look, 1.);
-                rt[k].camera = &c[k];
-                rt[k].scene = &scene;
-                rt[k].device = (int)((size_t)k % devices.size());   // context slot, see sppm_host::Device::get
-                rt[k].replica = (uint32_t)(i * 4 + k);
-                film[k] = films.on(devices[(size_t)rt[k].device]);
+                const size_t slot = (size_t)(i * 4 + k) % devices.size();   // context slot, see sppm_host::Device::get
+                Camera& c = cams[slot];
+                c = camera;
+                c.MoveTo(camera.pos + 0.00015 * Vec3::GetUnitRandVec());
+                c.lookAt(camera.look, 1.);
+                RayTracer rt;
+                rt.camera = &c;
+                rt.scene = &scene;
+                rt.device = (int)slot;
+                rt.replica = (uint32_t)(i * 4 + k);
+                rt.render_into(films.on(devices[slot]));
+                std::cerr << "Thread " << k << " done" << std::endl;
             }
-            std::vector<std::thread> th;
-            std::vector<std::string> errors(4);
-            for (int j = 0; j < 4; j++)
-                th.emplace_back([&, j]() {
-                    try { rt[j].render_into(film[j]); } catch (const std::exception& e) { errors[j] = e.what(); }
-                    std::cerr << "Thread " << j << " done" << std::endl;
-                });
-            for (auto& t : th) t.join();
-            for (const std::string& e : errors) if (!e.empty()) throw std::runtime_error(e);
-            for (size_t slot = 0; slot < std::min<size_t>(4, devices.size()); slot++) {   // what the queued passes ran into
+            const bool last = i + 1 == sppmtime;
+            const bool save = (i + 1) % save_every == 0 || last, keep = ckpt && *ckpt && ((i + 1) % ckpt_every == 0 || last);
+            if (!save && !keep) continue;
+            // A picture or checkpoint: the host waits for the contexts and hears what the queued passes ran into (a queue
+            // that overflowed is remembered until then).  In between, the next iterations' passes queue up behind and the
+            // GPU never drains.
+            for (size_t slot = 0; slot < devices.size(); slot++) {
                 sppm_host::Device& dev = sppm_host::Device::get((int)slot);
                 std::lock_guard<std::mutex> g(dev.mu);
                 dev.check(sppm_synchronize(dev.ctx), "sppm_synchronize");
             }
-            const bool last = i + 1 == sppmtime;
-            if ((i + 1) % save_every == 0 || last) {
+            if (save) {
                 std::string pic = std::string("aaanew") + std::to_string(i / 10) + std::string(".ppm");
                 std::cerr << "save:" << pic << std::endl;
                 if (!sppm_host::write_ppm(pic, camera.w, camera.h, films.tonemapped((i + 1) * 4.))) std::cerr << "cannot write " << pic << std::endl;
             }
-            if (ckpt && *ckpt && ((i + 1) % ckpt_every == 0 || last))
+            if (keep)
                 if (!sppm_host::save_checkpoint(ckpt, films, i + 1)) std::cerr << "cannot write " << ckpt << std::endl;
         }
     }

@@ -136,6 +136,12 @@ def load_library(path=None):
     # the one loaded second reports "no HIP GPUs".  Loaded after torch, this library binds to torch's copy and
     # all is well, so a process that has torch (bench.py and the multi-GPU host do use it, for streams and RCCL)
     # lets torch load first.  SPPM_NO_TORCH_PRELOAD=1 skips this for a host that never touches torch.
+    # Several contexts on one GPU (iterations in flight) want a hardware queue each: HIP's default of 4 queues per process
+    # folds more streams than that onto shared queues, whose kernels then run one after the other.  The runtime reads
+    # the variable when it starts; a host that has already used the GPU keeps what it had.
+    # SPPM_HW_QUEUES=0 leaves the environment alone.
+    if os.environ.get("SPPM_HW_QUEUES", "8") != "0":
+        os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("SPPM_HW_QUEUES", "8")
     if "torch" not in sys.modules and not os.environ.get("SPPM_NO_TORCH_PRELOAD"):
         import importlib.util
         if importlib.util.find_spec("torch") is not None:

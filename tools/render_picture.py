@@ -6,6 +6,7 @@ Raytracer.h:429-447) into a film on the GPU and writes the tone-mapped picture:
 
 The picture is what the reference hands to cv::imwrite (rows flipped, BGR bytes: Raytracer.h:460-470), written here
 in RGB order so that a viewer shows the colours the reference's JPEG shows."""
+import os
 import sys
 import time
 
@@ -19,14 +20,14 @@ def main():
     config, iters, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     factory, (w, h), rounds, per_round = scenes.CONFIGS[config]
     scene = factory()
-    ctxs = [SppmContext(0), SppmContext(0)]
+    ctxs = [SppmContext(0) for _ in range(int(os.environ.get("SPPM_INFLIGHT", "3")))]
     for c in ctxs:
         c.set_scene(scene)
     film = Film(w, h)
     rng = np.random.default_rng(1)
     t0 = time.perf_counter()
     for i in range(iters):
-        c = ctxs[i % 2]
+        c = ctxs[i % len(ctxs)]
         j = rng.normal(size=3)
         c.eye_pass(scenes.default_camera(w, h, jitter=0.00015 * j / np.linalg.norm(j)), 20260101, i)
         c.photon_pass(rounds, per_round, 20260101, i)
