@@ -13,6 +13,8 @@
 //                full): the HitPoints of a cell share one sweep over the deposits of the 27 cells
 //                around them, rows of 64 deposits held in registers; no atomics on HitPoints in the main kernel
 //   resolve    : k_resolve (tao -> flux image) or k_film_add (-> fp64 image sum), k_tonemap
+// Several contexts on one GPU (SPPM iterations in flight) launch their persistent grids small enough for a trace
+// workgroup of one and gather workgroups of another to be resident on a CU together (sppm_ctx::trace_blocks_per_cu).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -811,7 +813,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_reduce_close(const uint32
 #define GATHER_ROWS 3        // 78 VGPRs: three gather workgroups and one trace workgroup fit a CU's register files together
 #endif
 #ifndef GATHER_TILE
-#define GATHER_TILE 16u      // HitPoints per tile (<= 64: one accumulator lane each)
+#define GATHER_TILE 16u      // HitPoints per tile (<= 16: one accumulator lane per HitPoint in every DPP row)
 #endif
 
 // Sum over the 16 lanes of each DPP row, left in every lane of the row.
@@ -1757,7 +1759,8 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
     HIPCHK(ctx->nres.reserve(task_cap));
     unsigned long long* sc = ctx->scalars();
     const int max_blocks = trace_max_blocks(ctx);
-    // persistent workgroups: as many as stay resident (2 per CU with in-wave solves, 3 without), not more
+    // persistent workgroups: as many as stay resident (2 per CU with in-wave solves, 3 without), not more; one per CU
+    // when other contexts share the GPU
     auto blocks_for = [&](uint64_t items, bool coop) {
         const int per_cu = (mode == MODE_EYE && ctx->eye_blocks_per_cu > 0) ? ctx->eye_blocks_per_cu
                            : ctx->trace_blocks_per_cu > 0 ? ctx->trace_blocks_per_cu
