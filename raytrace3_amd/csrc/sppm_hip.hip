@@ -224,6 +224,9 @@ struct TraceParams {
     // pixels are spread over the image, so the rays that meet a Bezier object are a few lanes of every wave
     // (as photons are) instead of all lanes of a few waves, and can be solved in place without idling the rest.
     unsigned long long pix_mul;
+    // floor(2^64 / (w * h)) and floor(2^32 / w): the pixel of a work item and its row and column come from multiplications
+    // by these and a correction step instead of 64-bit divisions (a few hundred instructions per refill otherwise)
+    unsigned long long npx_magic; uint32_t w_magic;
     RawHit* hits; unsigned long long* n_hits; unsigned long long hit_cap;   // n_hits: claimed slots
     unsigned long long* n_real_hits;                                          // HitPoints written
     uint32_t* hcount;                                                         // HitPoints per grid bucket (the histogram of their counting sort)
@@ -341,10 +344,22 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
                     }
                 } else {
                     unsigned long long g = tp.fresh_first + (my - n_resume);
-                    if (MODE == MODE_EYE) g = (g * tp.pix_mul) % ((unsigned long long)tp.w * (unsigned long long)tp.h);   // see TraceParams::pix_mul
+                    uint32_t prow = 0, pcol = 0;
+                    if (MODE == MODE_EYE) {   // pixel (g * pix_mul) mod (w * h), see TraceParams::pix_mul; g, pix_mul < w * h <= 2^28
+                        const unsigned long long npx = (unsigned long long)tp.w * (unsigned long long)tp.h, x = g * tp.pix_mul;
+                        unsigned long long r = x - __umul64hi(x, tp.npx_magic) * npx;      // the quotient estimate is at most 2 short
+                        if (r >= npx) r -= npx;
+                        if (r >= npx) r -= npx;
+                        g = r;
+                        const uint32_t p = (uint32_t)r, w32 = (uint32_t)tp.w;
+                        prow = __umulhi(p, tp.w_magic);
+                        pcol = p - prow * w32;
+                        if (pcol >= w32) { pcol -= w32; prow++; }
+                        if (pcol >= w32) { pcol -= w32; prow++; }
+                    }
                     id = (uint32_t)g; dep = 0; node = 0;
                     if (MODE == MODE_EYE) {
-                        const int row = (int)(g / (unsigned long long)tp.w), col = (int)(g % (unsigned long long)tp.w);
+                        const int row = (int)prow, col = (int)pcol;
                         o = ld3(tp.pos);
                         // Camera::emit(y = row, x = col), Camera.h:18-22
                         d = get_unit(ld3(tp.du) * ((col + 0.5) / tp.w - 0.5) + ld3(tp.dv) * ((row + 0.5) / tp.h - 0.5) + ld3(tp.dir));
@@ -1878,6 +1893,8 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
         for (int k = 0; k < 3; k++) { tp.pos[k] = cam->pos[k]; tp.dir[k] = cam->dir[k]; tp.du[k] = cam->du[k]; tp.dv[k] = cam->dv[k]; }
         tp.w = cam->w; tp.h = cam->h;
         tp.pix_mul = ctx->eye_scatter ? coprime_near(npx, (uint64_t)((double)npx * 0.6180339887)) : 1;
+        tp.npx_magic = npx > 1 ? (unsigned long long)((((unsigned __int128)1) << 64) / npx) : ~0ull;
+        tp.w_magic = cam->w > 1 ? (uint32_t)((1ull << 32) / (uint64_t)cam->w) : 0xffffffffu;
         tp.hits = ctx->raw.p; tp.n_hits = ctx->scalars() + SC_HITS; tp.hit_cap = hit_cap;
         tp.n_real_hits = ctx->scalars() + SC_REAL_HITS;
         tp.counters = ctx->counters.p;

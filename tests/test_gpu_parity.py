@@ -374,6 +374,24 @@ def test_random_rooms_whole_iteration(gpu, with_teapot):
         print(f"room {trial}: {len(c)} HitPoints, {co['deposits']} deposits, image within tolerance {(diff <= 1e-3).mean():.4f}, MAE/mean {diff.mean():.2e}")
 
 
+@pytest.mark.parametrize("w,h", [(1, 1), (1, 64), (64, 1), (7, 5), (333, 77), (1021, 3)])
+def test_eye_pass_covers_every_pixel_once_at_odd_resolutions(gpu, w, h):
+    """Work item k of the eye pass is pixel (k * m) mod (w * h), its row and column found by multiplications with
+    precomputed reciprocals and a correction step: at widths and pixel counts that are 1, prime or otherwise awkward
+    the HitPoints are still those of the oracle, pixel for pixel."""
+    scene = scenes.scene_spheres_plane(True)
+    cam = scenes.default_camera(w, h)
+    gpu.set_scene(scene)
+    gpu.eye_pass(cam, SEED)
+    o = _oracle(scene)
+    o.eye_pass(cam, SEED)
+    g, c = gpu.hitpoints(), o.hitpoints()
+    assert np.array_equal(np.sort(_key(g)), np.sort(_key(c)))
+    assert g["x"].max(initial=0) < h and g["y"].max(initial=0) < w          # x = row, y = column
+    direct = g[g["node"] == 0]
+    assert len(np.unique(direct["x"].astype(np.int64) * w + direct["y"])) == len(direct)
+
+
 def test_empty_and_error_paths(gpu):
     from raytrace3_amd import SppmError
     fresh = SppmContext(0)
