@@ -115,3 +115,49 @@ def test_film_argument_checks():
             Film(0, 4)
     finally:
         film.close(); c.close()
+
+
+def test_five_contexts_in_flight_add_up_like_one():
+    """Five contexts on one GPU, used in turn with nothing but the eye pass's own wait between them (bench.py's loop:
+    their persistent grids share the CUs, their adds meet in one film), against the same replicas run one after the
+    other by a single context: the same HitPoints per replica, the same image sum up to the order of the additions."""
+    scene = scenes.scene_teapot(1)
+    w, h, n_iter = 160, 120, 15
+    rng = np.random.default_rng(11)
+    cams = []
+    for _ in range(n_iter):
+        j = rng.normal(size=3)
+        cams.append(scenes.default_camera(w, h, jitter=0.00015 * j / np.linalg.norm(j)))
+    ctxs = [SppmContext(0) for _ in range(5)]
+    film = Film(w, h)
+    try:
+        for c in ctxs:
+            c.set_scene(scene)
+        for i, cam in enumerate(cams):
+            c = ctxs[i % len(ctxs)]
+            c.eye_pass(cam, SEED, i)
+            c.photon_pass(300, 100, SEED, i)
+            film.add(c)
+        for c in ctxs:
+            c.synchronize()
+        together = film.read()
+        counts = [c.counters() for c in ctxs]
+    finally:
+        film.close()
+        for c in ctxs:
+            c.close()
+    one = SppmContext(0)                # alone on the GPU now: full grids, one pass after the other
+    try:
+        one.set_scene(scene)
+        alone = np.zeros((h, w, 3))
+        for i, cam in enumerate(cams):
+            one.eye_pass(cam, SEED, i)
+            one.photon_pass(300, 100, SEED, i)
+            alone += one.resolve()
+            if i >= n_iter - 5:         # the last pass of each of the five contexts: tallies equal to the lone context's
+                ca, cb = counts[i % 5], one.counters()
+                assert all(ca[k] == cb[k] for k in ("photons", "segments", "deposits", "candidates", "accepted", "hitpoints")), (i, ca, cb)
+    finally:
+        one.close()
+    assert alone.sum() > 0
+    assert np.allclose(together, alone, rtol=2e-4, atol=1e-6 * alone.mean())
