@@ -58,10 +58,11 @@ struct NewtonTask { uint32_t park, patch; };
 
 struct SceneParams {
     const char* blob;
-    int blob_bytes, off_box, off_cp, off_pobj, n_objs, n_patches;
+    int blob_bytes, off_box, off_cp, off_pobj, off_sub, n_objs, n_patches;   // off_sub < 0: the sub-patch boxes are not in the blob
     const uchar4* texels;
     const float* pw_q;      // Newton tables: power-basis coefficients around the patch centre, n_patches x 48
     const double* pw_c;     // and the centres, n_patches x 3
+    const float* sub_box;   // boxes of the 4 x 4 sub-patches of every patch (SceneView::sub_box) where the blob has no room for them, or null
 };
 
 struct DevCounters {
@@ -117,6 +118,7 @@ __device__ __forceinline__ SceneView stage_scene(const SceneParams& sp) {
     S.patch_cp = (const float*)(base + sp.off_cp);
     S.pw_q = sp.pw_q;
     S.pw_c = sp.pw_c;
+    S.sub_box = sp.off_sub >= 0 ? (const float*)(base + sp.off_sub) : sp.sub_box;
     S.patch_obj = (const int*)(base + sp.off_pobj);
     S.n_objs = sp.n_objs;
     S.n_patches = sp.n_patches;
@@ -1294,11 +1296,13 @@ struct sppm_ctx {
     std::string err;
     // scene
     bool have_scene = false;
-    DevBuf<char> blob; int blob_bytes = 0, off_box = 0, off_cp = 0, off_pobj = 0, n_objs = 0, n_patches = 0;
+    DevBuf<char> blob; int blob_bytes = 0, off_box = 0, off_cp = 0, off_pobj = 0, off_sub = -1, n_objs = 0, n_patches = 0;
     bool scene_in_lds = true;             // the scene tables fit the LDS staging area (else: read from global memory)
     bool coop_only = false;               // more patches than a parked ray's patch mask can name: rays are never parked
     DevBuf<uchar4> texels;
     DevBuf<float> pw_q; DevBuf<double> pw_c;   // Newton tables (power basis around the patch centres)
+    DevBuf<float> sub_box;                     // boxes of the sub-patches (subbox_prune); SPPM_SUBBOX=0: not used
+    bool use_sub_box = true;
     DevBuf<DevLight> lights; int n_lights = 0;
     // eye pass
     bool have_eye = false;
@@ -1377,6 +1381,8 @@ struct sppm_ctx {
         sp.blob = blob.p; sp.blob_bytes = blob_bytes; sp.off_box = off_box; sp.off_cp = off_cp; sp.off_pobj = off_pobj;
         sp.n_objs = n_objs; sp.n_patches = n_patches; sp.texels = texels.p;
         sp.pw_q = pw_q.p; sp.pw_c = pw_c.p;
+        sp.off_sub = off_sub;
+        sp.sub_box = (use_sub_box && n_patches > 0 && off_sub < 0) ? sub_box.p : nullptr;
         return sp;
     }
 };
@@ -1463,6 +1469,7 @@ int sppm_create(sppm_ctx** out, int device_id) {
     if (const char* b = getenv("SPPM_PLACE")) ctx->place_enabled = atoi(b) != 0;
     if (const char* b = getenv("SPPM_PLACE_SIGMA")) { ctx->place_sigma = std::max(0.0f, (float)atof(b)); if (ctx->place_sigma == 0.0f) ctx->place_add = 0; }
     if (const char* b = getenv("SPPM_VERBOSE")) ctx->verbose = atoi(b) != 0;
+    if (const char* b = getenv("SPPM_SUBBOX")) ctx->use_sub_box = atoi(b) != 0;
     if (ctx->ctl.reserve(ctx->ctl_words()) != hipSuccess || ctx->counters.reserve(1) != hipSuccess) {
         (void)hipStreamDestroy(ctx->own_stream);
         delete ctx;
@@ -1479,7 +1486,7 @@ void sppm_destroy(sppm_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    ctx->pw_q.release(); ctx->pw_c.release();
+    ctx->pw_q.release(); ctx->pw_c.release(); ctx->sub_box.release();
     ctx->blob.release(); ctx->texels.release(); ctx->lights.release();
     ctx->raw.release(); ctx->park[0].release(); ctx->park[1].release(); ctx->ntask[0].release(); ctx->ntask[1].release(); ctx->nres.release();
     ctx->hist.release(); ctx->hstart.release();
@@ -1510,11 +1517,58 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));   // passes still queued read the tables replaced below
     const int no = s->n_objects, np = s->n_patches;
+    // Boxes of the 4 x 4 sub-patches of every patch (subbox_prune): the control points of the sub-patch over
+    // [iu/4, (iu+1)/4] x [iv/4, (iv+1)/4] are blossom values of the patch (de Casteljau with one parameter per level), their
+    // box is grown by the margin and rounded outwards to fp32.
+    std::vector<float> sb;
+    if (ctx->use_sub_box && np > 0) {
+        auto blossom = [](const double c[4], double t1, double t2, double t3) {
+            const double a0 = c[0] + (c[1] - c[0]) * t1, a1 = c[1] + (c[2] - c[1]) * t1, a2 = c[2] + (c[3] - c[2]) * t1;
+            const double b0 = a0 + (a1 - a0) * t2, b1 = a1 + (a2 - a1) * t2;
+            return b0 + (b1 - b0) * t3;
+        };
+        auto segment = [&](const double c[4], double a, double b, double out[4]) {
+            out[0] = blossom(c, a, a, a); out[1] = blossom(c, a, a, b); out[2] = blossom(c, a, b, b); out[3] = blossom(c, b, b, b);
+        };
+        sb.assign((size_t)np * 16 * 6, 0.0f);
+        for (int p = 0; p < np; p++)
+            for (int iv = 0; iv < 4; iv++)
+                for (int iu = 0; iu < 4; iu++) {
+                    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+                    for (int k = 0; k < 3; k++) {
+                        double R[4][4];                                   // rows cut to the u segment: R[j][.] for row j (v index)
+                        for (int j = 0; j < 4; j++) {
+                            double c[4];
+                            for (int i = 0; i < 4; i++) c[i] = s->patches[(size_t)p * 48 + (j * 4 + i) * 3 + k];   // P[4 j + i], i along u
+                            segment(c, iu / 4.0, (iu + 1) / 4.0, R[j]);
+                        }
+                        for (int i = 0; i < 4; i++) {                     // columns cut to the v segment
+                            const double c[4] = {R[0][i], R[1][i], R[2][i], R[3][i]};
+                            double q[4];
+                            segment(c, iv / 4.0, (iv + 1) / 4.0, q);
+                            for (int j = 0; j < 4; j++) { lo[k] = std::min(lo[k], q[j]); hi[k] = std::max(hi[k], q[j]); }
+                        }
+                    }
+                    float* o = sb.data() + ((size_t)p * 16 + (size_t)(iv * 4 + iu)) * 6;
+                    for (int k = 0; k < 3; k++) {
+                        o[k] = std::nextafterf((float)(lo[k] - SPPM_SUBBOX_MARGIN), -INFINITY);
+                        o[3 + k] = std::nextafterf((float)(hi[k] + SPPM_SUBBOX_MARGIN), INFINITY);
+                    }
+                }
+    }
     const int off_box = (int)(((size_t)no * sizeof(DevObject) + 15) & ~(size_t)15);
     const int off_cp = off_box + np * 6 * (int)sizeof(double);
     const int off_pobj = off_cp + np * 48 * (int)sizeof(float);
-    const int bytes = (off_pobj + np * (int)sizeof(int) + 15) & ~15;
+    int bytes = (off_pobj + np * (int)sizeof(int) + 15) & ~15;
+    // the sub-patch boxes ride in the blob (and so in LDS) where that keeps it within the staging area
+    int off_sub = -1;
+    if (!sb.empty() && (size_t)bytes + sb.size() * sizeof(float) <= SCENE_LDS_MAX) { off_sub = bytes; bytes += (int)(sb.size() * sizeof(float)); }
     std::vector<char> blob((size_t)bytes, 0);
+    if (off_sub >= 0) memcpy(blob.data() + off_sub, sb.data(), sb.size() * sizeof(float));
+    else if (!sb.empty()) {
+        HIPCHK(ctx->sub_box.reserve(sb.size()));
+        HIPCHK(hipMemcpy(ctx->sub_box.p, sb.data(), sb.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     DevObject* objs = (DevObject*)blob.data();
     double* box = (double*)(blob.data() + off_box);
     float* cp = (float*)(blob.data() + off_cp);
@@ -1605,7 +1659,7 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
     }
     HIPCHK(ctx->blob.reserve((size_t)bytes));
     HIPCHK(hipMemcpy(ctx->blob.p, blob.data(), (size_t)bytes, hipMemcpyHostToDevice));
-    ctx->blob_bytes = bytes; ctx->off_box = off_box; ctx->off_cp = off_cp; ctx->off_pobj = off_pobj; ctx->n_objs = no; ctx->n_patches = np;
+    ctx->blob_bytes = bytes; ctx->off_box = off_box; ctx->off_cp = off_cp; ctx->off_pobj = off_pobj; ctx->off_sub = off_sub; ctx->n_objs = no; ctx->n_patches = np;
     // Large scenes: tables beyond the LDS staging area are read from global memory, and with more patches than the patch
     // mask of a parked ray holds every Bezier solve happens in the tracing wave (the default anyway).
     ctx->scene_in_lds = bytes <= SCENE_LDS_MAX;

@@ -536,6 +536,34 @@ def test_a_reused_context_gives_what_fresh_contexts_give():
         worn.close()
 
 
+def test_solves_skipped_by_the_sub_patch_boxes_change_nothing(monkeypatch):
+    """Patches none of whose sixteen grown sub-patch boxes the ray meets are not solved: with the table on (the default)
+    and off (SPPM_SUBBOX=0) every HitPoint is the same to the last bit and the photon pass counts the same segments,
+    deposits and updates, with the table in LDS (one teapot), in global memory beside LDS tables (four) and with every
+    table in global memory (ten)."""
+    for n_teapots, (w, h) in ((1, (160, 120)), (4, (120, 90)), (10, (96, 72))):
+        scene, cam = scenes.scene_teapot(n_teapots) if n_teapots <= 4 else _room_with_teapots(n_teapots - 4), scenes.default_camera(w, h)
+        got = []
+        for switch in ("0", "1"):
+            monkeypatch.setenv("SPPM_SUBBOX", switch)
+            ctx = SppmContext(0)
+            try:
+                ctx.set_scene(scene)
+                ctx.eye_pass(cam, SEED)
+                hp = ctx.hitpoints()
+                size = hp.dtype.itemsize
+                raw = hp.tobytes()
+                rows = sorted(raw[i * size:(i + 1) * size] for i in range(len(hp)))
+                ctx.photon_pass(200, 100, SEED)
+                got.append((rows, ctx.counters()))
+            finally:
+                ctx.close()
+        (rows0, c0), (rows1, c1) = got
+        assert len(rows0) > 0 and rows0 == rows1, n_teapots
+        assert all(c0[x] == c1[x] for x in ("photons", "segments", "deposits", "candidates", "accepted", "eye_segments")), (n_teapots, c0, c1)
+        assert c1["newton_calls"] < 0.8 * c0["newton_calls"], (n_teapots, c0["newton_calls"], c1["newton_calls"])
+
+
 def test_contexts_and_films_release_their_memory():
     """Create, use and destroy contexts and films over and over: the GPU's free memory comes back."""
     import torch
