@@ -183,6 +183,33 @@ def test_bezier_nearest_hit_over_many_patches(gpu):
     assert np.median(derr) < 1e-4 and (derr < 1e-3).mean() >= 0.97 and derr.max() < 0.05
 
 
+def test_axis_parallel_rays_through_the_teapot(gpu):
+    """Rays with exact zeros in two direction components, from all six sides through the teapot: the slab tests of the
+    patch boxes and of the sub-patch boxes divide by those zeros, and must still keep every patch the oracle finds a hit on."""
+    scene = scenes.scene_teapot(1, textured=False)
+    gpu.set_scene(scene)
+    o = _oracle(scene)
+    a, b = np.meshgrid(np.linspace(0.37, 14.2, 36), np.linspace(103.1, 136.9, 64), indexing="ij")       # (y, z) lattice
+    c, e = np.meshgrid(np.linspace(4.3, 35.7, 64), np.linspace(103.1, 136.9, 64), indexing="ij")        # (x, z)
+    f, h = np.meshgrid(np.linspace(4.3, 35.7, 64), np.linspace(0.37, 14.2, 36), indexing="ij")          # (x, y)
+    org, d = [], []
+    for x0, sx in ((2.0, 1.0), (45.0, -1.0)):
+        org.append(np.stack([np.full(a.size, x0), a.ravel(), b.ravel()], 1)); d.append(np.tile([sx, 0.0, 0.0], (a.size, 1)))
+    for y0, sy in ((0.5, 1.0), (40.0, -1.0)):
+        org.append(np.stack([c.ravel(), np.full(c.size, y0), e.ravel()], 1)); d.append(np.tile([0.0, sy, 0.0], (c.size, 1)))
+    for z0, sz in ((95.0, 1.0), (150.0, -1.0)):
+        org.append(np.stack([f.ravel(), h.ravel(), np.full(f.size, z0)], 1)); d.append(np.tile([0.0, 0.0, sz], (f.size, 1)))
+    org, d = np.concatenate(org), np.concatenate(d)
+    g, c = gpu.near_collide(org, d, SEED), o.near_collide(org, d, SEED)
+    bez = c["obj"] >= 8
+    assert bez.sum() > 3000
+    same = g["obj"] == c["obj"]
+    assert same[bez].mean() >= 0.99 and same[~bez].mean() >= 0.99
+    both = bez & same
+    derr = np.abs(g["dist"][both] - c["dist"][both])
+    assert np.median(derr) < 1e-4 and (derr < 1e-3).mean() >= 0.97 and derr.max() < 0.05
+
+
 def _compare_hitpoints(g, c, pos_tol, frac, bezier_objs=()):
     assert len(g) > 0
     kg, kc = _key(g), _key(c)
