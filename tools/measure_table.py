@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Runs on the GPU box: fills the measurement table of BASELINE.md / DESIGN.md.
+"""Runs on the GPU box: measures every configuration on the CPU oracle and on the GPU (the table of measurements in the documentation).
 CPU rows: the oracle's literal restatement of the reference (fp64, global MWC stream, kd-tree radius
 search, per-round update() sweep), one replica per thread like the reference's OpenMP loop, on a
 bounded photon sample; GPU rows: bench.py per configuration.  Writes gpurun_out/table.json."""
