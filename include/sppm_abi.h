@@ -167,8 +167,11 @@ const char* sppm_last_error(const sppm_ctx* ctx);
  * Waits for the passes still queued on the context.  Scene tables of up to
  * 64 KiB (224 B per object + 244 B per Bezier patch; the reference's scene: 9
  * objects, 32 patches, 10 KiB) are staged in LDS by the kernels, larger ones are
- * read from global memory.  Capacity (SPPM_E_CAPACITY beyond it): 4096 objects,
- * 65536 patches, 2^30 texels. */
+ * read from global memory.  Every patch is also cut into 4 x 4 sub-patches whose
+ * boxes (384 B per patch) let the kernels skip solves that cannot find anything;
+ * they ride in the staged tables while those stay within the 64 KiB (the
+ * reference's scene: 22 KiB in all).  Capacity (SPPM_E_CAPACITY beyond it):
+ * 4096 objects, 65536 patches, 2^30 texels. */
 int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* scene);
 
 /* Pass 1: RayTracer::GetHitPoint + ViewTrace (raytracer/Raytracer.h:102-116,
