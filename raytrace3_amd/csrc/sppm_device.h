@@ -276,6 +276,27 @@ __device__ __forceinline__ float aabb_entry_lb(const double* __restrict__ box, d
     return t0;
 }
 
+// Both at once, for the loop that takes one ray at a time through an object's patches: can the ray meet the box grown by
+// the margin at all (fp32 slab test, every slab distance moved outwards by more than its rounding error, so a "no" is
+// certain whatever the size of the coordinates), and if so the lower bound of aabb_entry_lb.  AABBbox::intersect can only
+// say yes where this does, so the fp64 test is run only for rays that some box may be met by: most rays that enter the
+// object's box pass between its patches.
+__device__ __forceinline__ bool aabb_may_hit_lb(const double* __restrict__ box, d3 o, d3 d, float& lb) {
+    float t0 = 0.0f, t1 = 3.0e38f;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        // +-inf for a ray parallel to the axis: outside the slab the interval comes out empty, inside unbounded, and the
+        // NaN of 0 * inf or inf - inf is dropped by fminf / fmaxf (no constraint)
+        const float inv = __builtin_amdgcn_rcpf((float)comp(d, i));
+        const float a = ((float)(box[i] - comp(o, i)) - SPPM_PRUNE_MARGIN) * inv, b = ((float)(box[3 + i] - comp(o, i)) + SPPM_PRUNE_MARGIN) * inv;
+        const float lo = fminf(a, b), hi = fmaxf(a, b);
+        t0 = fmaxf(t0, fmaf(-fabsf(lo), 1e-6f, lo));
+        t1 = fminf(t1, fmaf(fabsf(hi), 1e-6f, hi));
+    }
+    lb = t0;
+    return t0 <= t1;
+}
+
 // ------------------------------------------------------------------ bicubic Bernstein evaluation (Bezier.h:69-111), fp32
 // S(u,v) = sum_i sum_k P[4i+k] b_k(u) b_i(v): u runs along the fast index.
 struct f3 { float x, y, z; };
@@ -537,9 +558,11 @@ __device__ __forceinline__ void bezier_coop(const SceneView& S, const DevObject&
         int pidx = -1;
         for (int base = 0; base < n_patches; base += 64) {
             int p = first_patch + base + lane;
-            bool ph = (base + lane < n_patches) && aabb_hit(S.patch_box + 6 * p, so, sd);      // Bezier3::intersect, Bezier.h:176-186
+            float lbf = 0.0f;
+            bool ph = (base + lane < n_patches) && aabb_may_hit_lb(S.patch_box + 6 * p, so, sd, lbf);
+            if (__ballot(ph)) ph = ph && aabb_hit(S.patch_box + 6 * p, so, sd);                // Bezier3::intersect, Bezier.h:176-186
             // lb >= 0, so the bit patterns order like the values and the selection below runs on scalars
-            uint32_t lbb = ph ? __float_as_uint(aabb_entry_lb(S.patch_box + 6 * p, so, sd)) : 0xffffffffu;
+            uint32_t lbb = ph ? __float_as_uint(lbf) : 0xffffffffu;
             if (S.sub_box && __ballot(ph)) subbox_prune(S.sub_box, first_patch + base, so, sd, ph, lbb);
             uint64_t pm = __ballot(ph);
             while (pm) {
