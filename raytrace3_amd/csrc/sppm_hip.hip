@@ -1516,6 +1516,8 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
     if (s->n_objects > (1 << 12)) return fail(ctx, SPPM_E_CAPACITY, "more than 4096 objects in one scene");
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));   // passes still queued read the tables replaced below
+    ctx->have_scene = false;                     // an upload that fails half way leaves no scene rather than a mixed one
+    ctx->have_eye = false;
     const int no = s->n_objects, np = s->n_patches;
     // Boxes of the 4 x 4 sub-patches of every patch (subbox_prune): the control points of the sub-patch over
     // [iu/4, (iu+1)/4] x [iv/4, (iv+1)/4] are blossom values of the patch (de Casteljau with one parameter per level), their
