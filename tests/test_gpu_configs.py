@@ -564,6 +564,27 @@ def test_solves_skipped_by_the_sub_patch_boxes_change_nothing(monkeypatch):
         assert c1["newton_calls"] < 0.8 * c0["newton_calls"], (n_teapots, c0["newton_calls"], c1["newton_calls"])
 
 
+@pytest.mark.parametrize("n_teapots,size", [(1, (800, 600)), (4, (1920, 1080))])
+def test_sub_patch_boxes_at_full_size(monkeypatch, n_teapots, size):
+    """The same at the full size of the bench scene and of the four-teapot configuration: all 480 k / 2.07 M HitPoints of the
+    eye pass are the same records with the table on and off."""
+    got = []
+    for switch in ("0", "1"):
+        monkeypatch.setenv("SPPM_SUBBOX", switch)
+        ctx = SppmContext(0)
+        try:
+            ctx.set_scene(scenes.scene_teapot(n_teapots))
+            ctx.eye_pass(scenes.default_camera(*size), 7)
+            hp = ctx.hitpoints()
+            raw = np.frombuffer(hp.tobytes(), dtype=np.uint8).reshape(len(hp), hp.dtype.itemsize)
+            got.append((raw[np.lexsort(raw.T[::-1])], ctx.counters()["newton_calls"]))
+        finally:
+            ctx.close()
+    assert len(got[0][0]) >= 0.99 * size[0] * size[1]
+    assert got[0][0].shape == got[1][0].shape and bool((got[0][0] == got[1][0]).all())
+    assert got[1][1] < 0.8 * got[0][1]
+
+
 def test_contexts_and_films_release_their_memory():
     """Create, use and destroy contexts and films over and over: the GPU's free memory comes back."""
     import torch
