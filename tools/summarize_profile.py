@@ -44,15 +44,16 @@ def main():
     tag, name = sys.argv[1], sys.argv[2]
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
-    stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
+    # a tag collected twice leaves the files of both runs behind (the process id is part of the name): the newest counts
+    stats = sorted(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     if stats:
-        shutil.copy(stats[0], os.path.join(dst, f"{name}_kernel_stats.csv"))
+        shutil.copy(stats[-1], os.path.join(dst, f"{name}_kernel_stats.csv"))
     bj = os.path.join(src, "bench_stats.json")
     if os.path.exists(bj):
         shutil.copy(bj, os.path.join(dst, f"{name}_bench.json"))
     out = defaultdict(dict)
     for sub in ("fetch", "write", "sq", "tcc", "sq2"):
-        for p in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+        for p in sorted(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]:
             for k, cs in pmc_table(p).items():
                 for cname, (s, n) in cs.items():
                     out[k][cname] = s / n
