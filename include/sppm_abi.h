@@ -274,6 +274,17 @@ typedef struct sppm_collision {
 int sppm_debug_near_collide(sppm_ctx* ctx, uint64_t n, const double* org, const double* dir,
                             uint64_t seed, uint32_t replica, sppm_collision* out);
 
+/* sppm_debug_near_collide for callers that cannot allocate GPU memory (code under HIP graph capture rules, tight serving
+ * loops, harnesses that forbid hipMalloc): NO COUNTERPART IN THE REFERENCE.  Same arguments, same kernel, same random
+ * streams and bit-identical results, but the call makes no hipMalloc / hipFree (the allocating entry point makes three
+ * of each per call): rays and collision records are staged through a static device array of the library (2.2 MiB, which
+ * every GPU the library runs on holds until the process ends), whose launch tallies a fill kernel clears first.
+ * Limit: n <= SPPM_NOALLOC_MAX_RAYS per call, SPPM_E_CAPACITY beyond it.  Every call on a GPU shares that GPU's array:
+ * calls from several host threads of one process take turns on a mutex; the array keeps the last call's rays and records. */
+#define SPPM_NOALLOC_MAX_RAYS 16384
+int sppm_near_collide_noalloc(sppm_ctx* ctx, uint64_t n, const double* org, const double* dir,
+                              uint64_t seed, uint32_t replica, sppm_collision* out);
+
 /* Parity hook: Bezier3::newton (raytracer/Bezier.h:112-159) for n (ray, patch)
  * pairs; out_tuv receives (t, u, v) or (1e20, 1e20, 1e20). */
 int sppm_debug_newton(sppm_ctx* ctx, uint64_t n, const double* org, const double* dir,

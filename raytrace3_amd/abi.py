@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsppm_hip.so")
 
 SPPM_OBJ_PLANE, SPPM_OBJ_SPHERE, SPPM_OBJ_BEZIER = 0, 1, 2
+NOALLOC_MAX_RAYS = 16384      # SPPM_NOALLOC_MAX_RAYS of include/sppm_abi.h
 
 
 class Material(C.Structure):
@@ -114,6 +115,8 @@ ABI_SYMBOLS = {
     "sppm_get_timings": (C.c_int, [C.c_void_p, C.POINTER(Timings)]),
     "sppm_debug_near_collide": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.c_uint64, C.c_uint32, C.c_void_p]),
+    "sppm_near_collide_noalloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                            C.c_uint64, C.c_uint32, C.c_void_p]),
     "sppm_debug_photon_deposits": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
                                              C.POINTER(C.c_double), C.c_uint64, C.POINTER(C.c_uint64)]),
     "sppm_debug_newton": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -254,13 +257,16 @@ class SppmContext:
         self._check(self.lib.sppm_get_timings(self._ctx, C.byref(t)), "sppm_get_timings")
         return t.as_dict()
 
-    def near_collide(self, org, dir, seed, replica=0):
+    def near_collide(self, org, dir, seed, replica=0, noalloc=False):
+        """Scene::NearCollide for a batch of rays.  noalloc=True takes the entry point that stages through the library's
+        static device array and allocates nothing (at most NOALLOC_MAX_RAYS rays per call)."""
         org = np.ascontiguousarray(org, dtype=np.float64)
         dir = np.ascontiguousarray(dir, dtype=np.float64)
         n = org.shape[0]
         out = np.zeros(n, dtype=COLLISION_DTYPE)
-        self._check(self.lib.sppm_debug_near_collide(self._ctx, n, _dptr(org), _dptr(dir), seed, replica,
-                                                     out.ctypes.data_as(C.c_void_p)), "sppm_debug_near_collide")
+        fn, name = ((self.lib.sppm_near_collide_noalloc, "sppm_near_collide_noalloc") if noalloc else
+                    (self.lib.sppm_debug_near_collide, "sppm_debug_near_collide"))
+        self._check(fn(self._ctx, n, _dptr(org), _dptr(dir), seed, replica, out.ctypes.data_as(C.c_void_p)), name)
         return out
 
     def newton(self, org, dir, patch, seed, replica=0):

@@ -1284,6 +1284,30 @@ uint32_t next_pow2(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p
 
 }  // namespace
 
+// ------------------------------------------------------------------ static scratch of sppm_near_collide_noalloc
+// The staging areas (rays in, collision records out) and the tally block of the entry point that allocates nothing live
+// in one file-scope device array: every GPU the library runs on holds its own copy, at its own address, until the
+// process ends.  Host code never passes the array's NAME to a kernel or a copy (on the host that name is a stand-in, not
+// a device address): sppm_create asks the runtime for the address once per device (hipGetSymbolAddress, with that device
+// current) and keeps it in g_scratch_ptr; every use below goes through that pointer.
+#define SPPM_NOALLOC_RAYS SPPM_NOALLOC_MAX_RAYS
+struct NoAllocScratch {
+    DevCounters counters;                              // tallies of the launch; must start at zero: cleared by a fill kernel
+    double org[3 * SPPM_NOALLOC_RAYS];
+    double dir[3 * SPPM_NOALLOC_RAYS];
+    sppm_collision out[SPPM_NOALLOC_RAYS];
+};
+static_assert(sizeof(NoAllocScratch) < (4u << 20), "the static scratch stays modest: under 4 MiB per GPU");
+static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
+static void* g_scratch_ptr[64];                        // per device: the address of that GPU's copy of `scratch`
+static std::mutex g_scratch_mu[64];                    // calls that use a GPU's copy take turns
+static std::mutex g_scratch_init_mu;
+
+// adds a launch's Newton tally to the context's counters (what k_debug_near_collide does directly in the allocating entry point)
+__global__ void k_add_newton_calls(DevCounters* dst, const DevCounters* src) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && src->newton_calls) atomicAdd(&dst->newton_calls, src->newton_calls);
+}
+
 // contexts alive per GPU of this process (see sppm_ctx::trace_blocks_per_cu)
 static std::atomic<int> g_live_contexts[64];
 static bool shares_gpu(int device) { return device >= 0 && device < 64 && g_live_contexts[device].load(std::memory_order_relaxed) > 1; }
@@ -1442,6 +1466,15 @@ int sppm_create(sppm_ctx** out, int device_id) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return SPPM_E_DEVICE;
     if (hipSetDevice(device_id) != hipSuccess) return SPPM_E_DEVICE;
+    if (device_id < 64) {
+        // this GPU's copy of the static scratch array: its address is asked for once per device, with the device current
+        std::lock_guard<std::mutex> g(g_scratch_init_mu);
+        if (!g_scratch_ptr[device_id]) {
+            void* p = nullptr;
+            if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return SPPM_E_DEVICE;
+            g_scratch_ptr[device_id] = p;
+        }
+    }
     sppm_ctx* ctx = new (std::nothrow) sppm_ctx();
     if (!ctx) return SPPM_E_NOMEM;
     ctx->device = device_id;
@@ -2295,6 +2328,40 @@ int sppm_debug_near_collide(sppm_ctx* ctx, uint64_t n, const double* org, const 
     } while (0);
     o.release(); d.release(); c.release();
     return rc;
+}
+
+// sppm_debug_near_collide without a single allocation: the rays and the collision records are staged through this
+// GPU's copy of the static scratch array (g_scratch_ptr[device], never the array's name), the launch's tally block sits
+// there as well and is cleared by a fill kernel first (the array keeps the last call's contents).  Same kernel, same random
+// streams, same results as the allocating entry point.  At most SPPM_NOALLOC_RAYS rays per call.
+int sppm_near_collide_noalloc(sppm_ctx* ctx, uint64_t n, const double* org, const double* dir, uint64_t seed, uint32_t replica,
+                              sppm_collision* out) {
+    if (!ctx || !org || !dir || !out) return SPPM_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, SPPM_E_INVALID, "sppm_set_scene must come first");
+    if (n == 0) return SPPM_OK;
+    if (n > SPPM_NOALLOC_RAYS)
+        return fail(ctx, SPPM_E_CAPACITY, "sppm_near_collide_noalloc takes at most " + std::to_string(SPPM_NOALLOC_RAYS) +
+                                              " rays per call (the static scratch array holds no more); split the batch or use sppm_debug_near_collide");
+    if (ctx->device < 0 || ctx->device >= 64 || !g_scratch_ptr[ctx->device]) return fail(ctx, SPPM_E_DEVICE, "no static scratch on this device");
+    HIPCHK(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> turn(g_scratch_mu[ctx->device]);     // the GPU's one array serves one call at a time
+    NoAllocScratch* s = (NoAllocScratch*)g_scratch_ptr[ctx->device];
+    HIPCHK(hipMemcpyAsync(s->org, org, 3 * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(s->dir, dir, 3 * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = launch_fill(ctx, (uint32_t*)&s->counters, sizeof(DevCounters) / 4, 0u)) return rc;
+    const uint32_t rng = host_rng_base(seed, replica * 4u + D_EYE);
+    if (ctx->scene_in_lds)
+        hipLaunchKernelGGL(k_debug_near_collide<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)ctx->blob_bytes, ctx->stream,
+                           ctx->scene_params(), (uint32_t)n, (const double*)s->org, (const double*)s->dir, rng, s->out, &s->counters);
+    else
+        hipLaunchKernelGGL(k_debug_near_collide<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           ctx->scene_params(), (uint32_t)n, (const double*)s->org, (const double*)s->dir, rng, s->out, &s->counters);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_add_newton_calls, dim3(1), dim3(64), 0, ctx->stream, ctx->counters.p, (const DevCounters*)&s->counters);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, s->out, n * sizeof(sppm_collision), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SPPM_OK;
 }
 
 int sppm_debug_photon_deposits(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_t photon_begin, uint64_t photon_count,
