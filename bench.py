@@ -149,6 +149,22 @@ def main():
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("SPPM_INFLIGHT", "5")),
                     help="replica iterations in flight per GPU (one context = one HIP stream each)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+
+    # `bench.py --gpus N` started by hand (no launcher around it, WORLD_SIZE unset): start the N ranks here, as CHILD
+    # processes of torch.distributed.run, before this process has imported torch or touched a GPU, and leave with their
+    # exit code.  Under a launcher (the driver's torch.distributed.run line) WORLD_SIZE is set and must equal --gpus.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import torch
     import torch.distributed as dist
@@ -158,22 +174,37 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly --gpus ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU.  SPPM_BENCH_SHARE_GPU=1 lets the ranks of a rehearsal share the GPUs there are (two ranks on a
+    # one-GPU box: the collective path runs for real, the numbers mean nothing)
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev and os.environ.get("SPPM_BENCH_SHARE_GPU") != "1":
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU of its own ({n_dev} visible); SPPM_BENCH_SHARE_GPU=1 shares them")
+    device_index = local_rank % n_dev
+    torch.cuda.set_device(device_index)
+    # RCCL refuses a communicator with two ranks on one GPU: a rehearsal that shares GPUs reduces the images with gloo
+    # over host copies instead (launch path, sharding and the world-size checks run for real; the collective does not)
+    via_host = world > 1 and world > n_dev
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if via_host:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the RCCL process group has {dist.get_world_size()} ranks")
+        world = dist.get_world_size()
 
     factory, (w, h), cfg_rounds, per_round = scenes.CONFIGS[args.config]
     rounds = args.rounds or cfg_rounds
     scene = factory()
     cam = scenes.default_camera(w, h)
-    ctxs = [SppmContext(local_rank) for _ in range(max(1, args.inflight))]
+    ctxs = [SppmContext(device_index) for _ in range(max(1, args.inflight))]
     # torch's view of each context's own HIP stream: the all-reduce of a context's image is issued under it, so it is
     # ordered with the context's passes by stream order and the host never waits inside the timed loop
-    streams = [torch.cuda.ExternalStream(c.stream_handle(), device=torch.device("cuda", local_rank)) for c in ctxs]
+    streams = [torch.cuda.ExternalStream(c.stream_handle(), device=torch.device("cuda", device_index)) for c in ctxs]
     for c in ctxs:
         c.set_scene(scene)
     ctx = ctxs[0]
@@ -184,7 +215,8 @@ def main():
 
     def step(i):
         k = i % len(ctxs)
-        D.sharded_iteration(ctxs[k], cam, SEED, i, total_rounds, per_round, n_lights, rank, world, pic_tensor=pics[k], stream=streams[k])
+        D.sharded_iteration(ctxs[k], cam, SEED, i, total_rounds, per_round, n_lights, rank, world, pic_tensor=pics[k], stream=streams[k],
+                            via_host=via_host)
 
     def fence():
         if world > 1:
@@ -193,7 +225,8 @@ def main():
 
     # set-up: every context allocates its buffers in its first iteration; keep that out of warm-up and timing
     for k in range(len(ctxs)):
-        D.sharded_iteration(ctxs[k], cam, SEED, 0, total_rounds, per_round, n_lights, rank, world, pic_tensor=pics[k], stream=streams[k])
+        D.sharded_iteration(ctxs[k], cam, SEED, 0, total_rounds, per_round, n_lights, rank, world, pic_tensor=pics[k], stream=streams[k],
+                            via_host=via_host)
     fence()
     for i in range(args.warmup):
         step(i)
@@ -208,7 +241,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if via_host else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # HIP-event durations measured on the library's stream(s) and tallies, summed over the timed steps
@@ -225,7 +258,7 @@ def main():
         ctxs[0].stats_mode(True)
         for i in range(ALONE_STEPS):
             D.sharded_iteration(ctxs[0], cam, SEED, args.warmup + args.steps + i, total_rounds, per_round, n_lights, rank, world,
-                                pic_tensor=pics[0], stream=streams[0])
+                                pic_tensor=pics[0], stream=streams[0], via_host=via_host)
         ctxs[0].synchronize()
         fence()
         tm1, cn1 = ctxs[0].timings(), ctxs[0].counters()

@@ -3,6 +3,7 @@
 // the C-ABI structs of sppm_abi.h and keeps one GPU context per device.
 #pragma once
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <map>
@@ -31,13 +32,24 @@ struct FlatScene {
     uint64_t tag = 0;
 };
 
+// The tag decides whether a context's copy of the scene is still current (Device::ensure_scene).  The reference reads the
+// live objects on every ray, so a host may change a material, a colour, a position or a texture between two passes: the
+// tag therefore hashes the flattened CONTENT (every field of every object, the control points, the lights, each
+// texture's size and texels), not the addresses of the objects.
 inline void flatten(const std::vector<Obj*>& objvec, const std::vector<Light*>& plvec, FlatScene& f) {
     f = FlatScene();
     std::vector<const Texture*> seen;
     uint64_t tag = 1469598103934665603ull;
     auto mix = [&](uint64_t v) { tag = (tag ^ v) * 1099511628211ull; };
+    auto mix_bytes = [&](const void* p, size_t n) {
+        const unsigned char* b = (const unsigned char*)p;
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, b + i, 8); mix(w); }
+        for (; i < n; i++) mix(b[i]);
+    };
     for (Obj* o : objvec) {
         sppm_object so;
+        std::memset(&so, 0, sizeof(so));               // padding bytes, if a compiler adds any, hash alike
         o->Describe(so, f.patches);
         if (const Texture* t = o->getTexture()) {
             size_t k = 0;
@@ -47,18 +59,20 @@ inline void flatten(const std::vector<Obj*>& objvec, const std::vector<Light*>& 
                 sppm_texture st;
                 st.rows = t->rows; st.cols = t->cols; st.texels = t->texels.data();
                 f.tex.push_back(st);
+                mix((uint64_t)t->rows); mix((uint64_t)t->cols);
+                mix_bytes(t->texels.data(), t->texels.size());
             }
             so.texture = (int)k;
         }
         f.objs.push_back(so);
-        mix((uint64_t)(uintptr_t)o);
-        mix((uint64_t)(uintptr_t)o->getTexture());
+        mix_bytes(&so, sizeof(so));
     }
+    mix_bytes(f.patches.data(), f.patches.size() * sizeof(double));
     for (Light* l : plvec) {
         sppm_light sl;
         for (int k = 0; k < 3; k++) { sl.pos[k] = l->position().val[k]; sl.color[k] = l->power().val[k]; }
         f.lights.push_back(sl);
-        mix((uint64_t)(uintptr_t)l);
+        mix_bytes(&sl, sizeof(sl));
     }
     mix(objvec.size()); mix(plvec.size());
     f.tag = tag;

@@ -31,7 +31,8 @@ def all_reduce_image(pic):
     return pic
 
 
-def sharded_iteration(ctx, cam, seed, replica, total_rounds, per_round, n_lights, rank, world, pic_tensor=None, stream=None):
+def sharded_iteration(ctx, cam, seed, replica, total_rounds, per_round, n_lights, rank, world, pic_tensor=None, stream=None,
+                      via_host=False):
     """One SPPM iteration of one replica on this rank's shard.  ctx is any object with the
     SppmContext methods; pic_tensor (device float32 [h,w,3]) receives the partial image and is
     all-reduced in place; without it the host image is returned un-reduced.
@@ -40,7 +41,10 @@ def sharded_iteration(ctx, cam, seed, replica, total_rounds, per_round, n_lights
     or a torch stream given to the context with ctx.set_stream(stream.cuda_stream)).  The
     collective is then issued under that stream, so it is ordered after the resolve, and whatever the context
     queues next after the collective, without the host waiting: iterations of other contexts keep the GPU busy
-    meanwhile.  Without it the host waits for the context before the collective."""
+    meanwhile.  Without it the host waits for the context before the collective.
+
+    via_host: the process group is gloo (ranks that share one GPU cannot form an RCCL communicator): the image is copied
+    to host memory, reduced there and copied back, each step synchronous (gloo only ever sees CPU tensors)."""
     total = total_rounds * per_round * n_lights
     begin, count = photon_shard(total, rank, world)
     ctx.eye_pass(cam, seed, replica)
@@ -51,6 +55,12 @@ def sharded_iteration(ctx, cam, seed, replica, total_rounds, per_round, n_lights
         ctx.photon_pass(total_rounds, per_round, seed, replica, photon_begin=total, photon_count=1)
     if pic_tensor is not None:
         ctx.resolve_device(pic_tensor.data_ptr())
+        if world > 1 and via_host:
+            ctx.synchronize()
+            host = pic_tensor.cpu()
+            all_reduce_image(host)
+            pic_tensor.copy_(host)
+            return pic_tensor
         if world > 1 and stream is not None:
             import torch
             with torch.cuda.stream(stream):     # the process group orders its own stream after and before this one
