@@ -74,7 +74,7 @@ def cpu_baseline(scene, w, h, rounds, threads):
     for c in ctxs:
         c.close()
     return {
-        "value": photons / t_ph / 1e6, "unit": "Mphotons/s", "cores": threads, "kind": "port",
+        "value": photons / t_ph / 1e6, "unit": "Mphotons/s", "cores": threads, "kind": "port", "host_nproc": os.cpu_count(),
         "sample": f"{threads} replicas x {rounds * 100} photons ({rounds} rounds x 100) on the {w}x{h} teapot scene, "
                   f"photon pass {t_ph:.1f} s (eye pass {t_eye:.1f} s not counted), oracle literal mode: fp64, kd-tree "
                   f"radius search, per-round update() sweep",
@@ -82,59 +82,59 @@ def cpu_baseline(scene, w, h, rounds, threads):
     }
 
 
-VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9      # CUs x SIMDs x lanes per cycle x 2.4 GHz: vector instructions per lane per second
+N_CU, N_SIMD, CLOCK_HZ = 256, 4, 2.4e9
+SIMD_CYCLES_PER_S = N_CU * N_SIMD * CLOCK_HZ                 # what the vector units of the chip offer, in SIMD-cycles
+PEAK_TLANE_CYCLES = SIMD_CYCLES_PER_S * 64 / 1e12            # ... and in lane-cycles: 64 lanes per SIMD-cycle of a busy vector unit
 
 
 def _kernel(d, name):
     """The summary's entry for a kernel, template arguments or not (k_gather, k_gather<true>)."""
     for k, v in d.items():
-        if k == name or k.startswith(name + "<"):
+        if k == name or k.startswith(name + "<") or (name.endswith("<1") and k.startswith(name)):
             return v
     return {}
 
 
-def _profiles(shared):
-    """The committed PMC summaries, oldest first, of the launch mode asked for: several iterations in flight (the
-    default command; its persistent grids are sized to share the GPU) or one."""
+def committed_profile(shared):
+    """The newest committed rocprofv3 summary (profiles/*_pmc.json + *_kernel_stats.csv) of the launch mode asked for:
+    several iterations in flight (the default command; its persistent grids are sized to share the GPU) or one.
+    Returns (per-kernel counters per launch, {kernel: share of GPU time}, file name) or None."""
+    import csv
     import glob
     want = "default" if shared else "single"
-    return [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))) if want in os.path.basename(f)]
-
-
-def measured_valu(shared):
-    """Vector instructions per launch of the two dominant kernels from the committed PMC profile
-    (SQ_INSTS_VALU, wave instructions): both kernels live on VALU issue, not on HBM."""
-    best = None
-    for f in _profiles(shared):
+    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=lambda f: (os.path.basename(f).split("_")[0:2]))
+             if want in os.path.basename(f)]
+    for f in reversed(files):
         try:
             with open(f) as fh:
                 d = json.load(fh)
-            tk = [v for k, v in d.items() if k.startswith("k_trace<1, true")]      # the photon pass with in-wave solves
-            g, t = _kernel(d, "k_gather").get("SQ_INSTS_VALU"), (tk[0].get("SQ_INSTS_VALU") if tk else None)
-            if g and t:
-                g += _kernel(d, "k_gather_split").get("SQ_INSTS_VALU") or 0.0
-                best = {"k_gather_wave_insts": float(g), "k_trace_photon_wave_insts": float(t), "source": "profiles/" + os.path.basename(f)}
         except (OSError, ValueError):
-            pass
-    return best
-
-
-def measured_traffic(shared):
-    """HBM bytes per gather (k_gather and k_gather_split) from the rocprofv3 PMC passes committed under profiles/
-    ((2 * FETCH_SIZE + WRITE_SIZE) * 1024, collected by tools/gpu_profile.sh on this same command);
-    None when no such profile is in the tree."""
-    best = None
-    for f in _profiles(shared):
+            continue
+        if not any(k.startswith("k_trace<1") for k in d):
+            continue
+        share = {}
         try:
-            with open(f) as fh:
-                d = json.load(fh)
-            t = _kernel(d, "k_gather").get("hbm_traffic_bytes_per_launch")
-            if t:      # the heavy-cell pieces are part of the same gather
-                t2 = _kernel(d, "k_gather_split").get("hbm_traffic_bytes_per_launch") or 0.0
-                best = (float(t) + float(t2), os.path.basename(f))
-        except (OSError, ValueError):
+            with open(f.replace("_pmc.json", "_kernel_stats.csv")) as fh:
+                for r in csv.DictReader(fh):
+                    share[r["Name"].replace("void ", "").split("(")[0]] = float(r["Percentage"]) / 100.0
+        except (OSError, ValueError, KeyError):
             pass
-    return best
+        return d, share, os.path.basename(f)
+    return None
+
+
+def valu_fields(c, seconds):
+    """Vector-unit figures of one launch from its SQ counters (per launch) and its duration.  SQ_ACTIVE_INST_VALU counts the
+    quad-cycles a wave has a vector instruction executing (an fp64 or transcendental instruction counts its longer issue),
+    SQ_THREAD_CYCLES_VALU the same weighted by the lanes enabled."""
+    act, thr, ins = c.get("SQ_ACTIVE_INST_VALU"), c.get("SQ_THREAD_CYCLES_VALU"), c.get("SQ_INSTS_VALU")
+    if not act or seconds <= 0:
+        return None
+    out = {"valu_busy_frac": act * 4.0 / (seconds * SIMD_CYCLES_PER_S), "valu_wave_instructions": ins}
+    if thr:
+        out["lanes_active"] = thr / act
+        out["lane_cycles"] = thr * 4.0
+    return out
 
 
 def main():
@@ -200,23 +200,27 @@ def main():
     factory, (w, h), cfg_rounds, per_round = scenes.CONFIGS[args.config]
     rounds = args.rounds or cfg_rounds
     scene = factory()
-    cam = scenes.default_camera(w, h)
+    # Every step renders another replica: its own random streams and, as in the reference's loop (Raytracer.h:434), a camera
+    # moved by 0.00015 x a random unit vector, so HitPoints, bucket count and deposit reach change from step to step.
+    jit = np.random.default_rng(SEED).normal(size=(64, 3))
+    cams = [scenes.default_camera(w, h, jitter=0.00015 * j / np.linalg.norm(j)) for j in jit]
     ctxs = [SppmContext(device_index) for _ in range(max(1, args.inflight))]
     # torch's view of each context's own HIP stream: the all-reduce of a context's image is issued under it, so it is
     # ordered with the context's passes by stream order and the host never waits inside the timed loop
     streams = [torch.cuda.ExternalStream(c.stream_handle(), device=torch.device("cuda", device_index)) for c in ctxs]
     for c in ctxs:
         c.set_scene(scene)
-    ctx = ctxs[0]
     n_lights = len(scene.light_list)
     per_rank = rounds * per_round * n_lights
     total_rounds = rounds * world
     pics = [torch.zeros((h, w, 3), dtype=torch.float32, device="cuda") for _ in ctxs]
 
+    def iteration(k, i):
+        D.sharded_iteration(ctxs[k], cams[i % len(cams)], SEED, i, total_rounds, per_round, n_lights, rank, world, pic_tensor=pics[k],
+                            stream=streams[k], via_host=via_host)
+
     def step(i):
-        k = i % len(ctxs)
-        D.sharded_iteration(ctxs[k], cam, SEED, i, total_rounds, per_round, n_lights, rank, world, pic_tensor=pics[k], stream=streams[k],
-                            via_host=via_host)
+        iteration(i % len(ctxs), i)
 
     def fence():
         if world > 1:
@@ -225,8 +229,7 @@ def main():
 
     # set-up: every context allocates its buffers in its first iteration; keep that out of warm-up and timing
     for k in range(len(ctxs)):
-        D.sharded_iteration(ctxs[k], cam, SEED, 0, total_rounds, per_round, n_lights, rank, world, pic_tensor=pics[k], stream=streams[k],
-                            via_host=via_host)
+        iteration(k, 0)
     fence()
     for i in range(args.warmup):
         step(i)
@@ -248,74 +251,111 @@ def main():
     tms, cnts = [c.timings() for c in ctxs], [c.counters() for c in ctxs]
     tm = {k: sum(t[k] for t in tms) for k in tms[0]}
     counters = {k: (sum(c[k] for c in cnts) if k != "hitpoints" else cnts[0][k]) for k in cnts[0]}
+    footprint = sum(c.device_stats()["device_bytes"] for c in ctxs)
     PHASES = ("eye_trace_ms", "grid_build_ms", "photon_trace_ms", "deposit_sort_ms", "gather_ms", "resolve_ms")
     acc = {k: tm[k] for k in PHASES}
     # The kernels' own durations: with several iterations in flight a HIP-event span also covers whatever the other
-    # stream ran in between, so the roofline figures come from a few more iterations with ONE in flight (same work,
+    # streams ran in between, so the roofline figures come from a few more iterations with ONE in flight (same work,
     # same stream and events, outside the timed region); rocprofv3 serialises kernels and reports these durations.
     ALONE_STEPS = 4
     if len(ctxs) > 1:
         ctxs[0].stats_mode(True)
         for i in range(ALONE_STEPS):
-            D.sharded_iteration(ctxs[0], cam, SEED, args.warmup + args.steps + i, total_rounds, per_round, n_lights, rank, world,
-                                pic_tensor=pics[0], stream=streams[0], via_host=via_host)
+            iteration(0, args.warmup + args.steps + i)
         ctxs[0].synchronize()
         fence()
-        tm1, cn1 = ctxs[0].timings(), ctxs[0].counters()
-        alone = {k: tm1[k] / ALONE_STEPS for k in PHASES}
-        alone_launches = tm1["gather_launches"]
-        alone_bytes = 40.0 * cn1["candidates"] + 32.0 * cn1["accepted"] + 64.0 * cn1["segments"]
+        tm1, cn1, ds1, alone_steps = ctxs[0].timings(), ctxs[0].counters(), ctxs[0].device_stats(), ALONE_STEPS
     else:
-        alone = {k: acc[k] / args.steps for k in PHASES}
-        alone_launches = tm["gather_launches"]
-        alone_bytes = 40.0 * counters["candidates"] + 32.0 * counters["accepted"] + 64.0 * counters["segments"]
-    alone_steps = ALONE_STEPS if len(ctxs) > 1 else args.steps
-    gather_launches = alone_launches
-    bytes_model = alone_bytes
+        tm1, cn1, ds1, alone_steps = tm, counters, ctxs[0].device_stats(), args.steps
+    alone = {k: tm1[k] / alone_steps for k in PHASES}
+    gl, tl = max(1, tm1["gather_launches"]), max(1, tm1["trace_launches"] // 2)      # per step: one eye and one photon trace launch
 
     if rank == 0:
         photons_total = per_rank * world * args.steps
-        # the committed rocprofv3 counters are of the default workload: they say nothing about another configuration
-        profiled = args.config == "c2_teapot_800x600" and rounds == cfg_rounds
-        traffic = measured_traffic(len(ctxs) > 1) if profiled else None
-        gather_s = alone["gather_ms"] * alone_steps / 1e3
-        achieved = bytes_model / gather_s / 1e9 if gather_s > 0 else 0.0
         pass_s = (alone["photon_trace_ms"] + alone["deposit_sort_ms"] + alone["gather_ms"]) / 1e3    # one photon pass, undisturbed
+        how = ("HIP events on the library's stream" + (f", {ALONE_STEPS} iterations with one iteration in flight after the timed region (spans of "
+               "the timed region include the other streams' kernels), launched as in the timed region: persistent grids sized to share "
+               "the GPU with the other contexts' kernels" if len(ctxs) > 1 else ", over the timed region"))
+        # the committed rocprofv3 counters are of the default workload: they say nothing about another configuration
+        prof = committed_profile(len(ctxs) > 1) if (args.config == "c2_teapot_800x600" and rounds == cfg_rounds) else None
+        pk, share, pname = prof if prof else ({}, {}, None)
+        src = (f"profiles/{pname}: rocprofv3 --pmc passes of this command, per-launch averages; HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; "
+               "kernels run one at a time under the profiler") if pname else None
+
+        # ---- dominant kernel: the photon trace (persistent wavefronts, fp64 ray state): bound by vector-instruction issue
+        trace_s = alone["photon_trace_ms"] * alone_steps / tl / 1e3
+        tc = _kernel(pk, "k_trace<1")
+        tv = valu_fields(tc, trace_s) if tc else None
+        lane_cycles = tv.get("lane_cycles") if tv else None
+        roofline = {
+            "kernel": "k_trace<MODE_PHOTON> (photon emission + PhotonTrace on persistent wavefronts; fp64 ray state, in-wave Bezier solves)",
+            "share_of_gpu_time": next((v for k, v in share.items() if k.startswith("k_trace<1")), None),
+            "bound": "valu", "unit": "Tlane-cycle/s", "peak": PEAK_TLANE_CYCLES,
+            "achieved": lane_cycles / trace_s / 1e12 if lane_cycles else None,
+            "frac": lane_cycles / trace_s / 1e12 / PEAK_TLANE_CYCLES if lane_cycles else None,
+            "frac_is": "lane-cycles with a vector instruction executing (SQ_THREAD_CYCLES_VALU x 4: fp64 and transcendental instructions at "
+                       "their real issue cost, disabled lanes not counted) / (256 CU x 4 SIMD x 64 lanes x 2.4 GHz x launch duration)",
+            "valu_busy_frac": tv["valu_busy_frac"] if tv else None, "lanes_active": tv.get("lanes_active") if tv else None,
+            "valu_wave_instructions_per_launch": tv["valu_wave_instructions"] if tv else None,
+            "traffic": tc.get("hbm_traffic_bytes_per_launch") if tc else None,
+            "hbm_frac": (tc["hbm_traffic_bytes_per_launch"] / trace_s / 1e9 / HBM_PEAK_GBS) if tc and tc.get("hbm_traffic_bytes_per_launch") else None,
+            "avg_launch_ms": trace_s * 1e3, "segments_per_launch": cn1["segments"] / tl,
+            "counters_source": src, "measured": how,
+        }
+        # ---- the gather: what HBM sees of it against what it must move, and its vector-unit figures
+        gather_s = alone["gather_ms"] * alone_steps / gl / 1e3
+        gc, gs = _kernel(pk, "k_gather"), _kernel(pk, "k_gather_split")
+        g_traffic = (gc.get("hbm_traffic_bytes_per_launch", 0.0) + gs.get("hbm_traffic_bytes_per_launch", 0.0)) if gc.get("hbm_traffic_bytes_per_launch") else None
+        both = {k: gc.get(k, 0.0) + gs.get(k, 0.0) for k in ("SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU") if gc.get(k)}
+        gv = valu_fields(both, gather_s) if both else None
+        stored, n_hp = ds1["stored_deposits"] / gl, cn1["hitpoints"]
+        compulsory = 64.0 * stored + 96.0 * n_hp                      # every kept deposit read once; HitPoint 32 + 16 + 16 + 16 B read, 16 B written
+        ref_bytes = (40.0 * cn1["candidates"] + 32.0 * cn1["accepted"] + 64.0 * cn1["segments"]) / gl
+        roofline_gather = {
+            "kernel": "k_gather + k_gather_split (the radius gather of one photon pass)",
+            "share_of_gpu_time": sum(v for k, v in share.items() if k.startswith("k_gather")) or None,
+            "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "achieved": g_traffic / gather_s / 1e9 if g_traffic else None,
+            "frac": g_traffic / gather_s / 1e9 / HBM_PEAK_GBS if g_traffic else None,
+            "traffic": g_traffic, "compulsory_bytes": compulsory,
+            "compulsory_is": "64 B per stored deposit read once + 96 B per HitPoint (position and key 32, normal 16, weight 16, tao read and written 16 + 16)",
+            "traffic_over_compulsory": g_traffic / compulsory if g_traffic and compulsory else None,
+            "reference_equivalent_bytes": ref_bytes,
+            "reference_equivalent_is": "40 B per pair in range + 32 B per accepted update + 64 B per photon segment: what the reference's radius search and "
+                                       "update loop touch per pass; divided by the launch duration it is a re-use figure, not a bandwidth",
+            "reuse_factor": ref_bytes / g_traffic if g_traffic else None,
+            "pair_tests_per_launch": ds1["pair_tests"] / gl,
+            "pairs_in_range_frac": cn1["candidates"] / ds1["pair_tests"] if ds1["pair_tests"] else None,
+            "valu_busy_frac": gv["valu_busy_frac"] if gv else None, "lanes_active": gv.get("lanes_active") if gv else None,
+            "valu_wave_instructions_per_launch": gv["valu_wave_instructions"] if gv else None,
+            "avg_launch_ms": gather_s * 1e3, "counters_source": src, "measured": how,
+        }
         out = {
             "metric": "Mphotons/s", "value": photons_total / elapsed / 1e6, "unit": "Mphotons/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 rays/gather + f32 Newton/flux", "data": "synthetic",
             "config": {"inflight": len(ctxs), "workload": f"{args.config}: teapot.bpt Cornell scene {w}x{h}, {per_rank} photons/iter/GPU "
-                                   f"({rounds} rounds x {per_round}), one replica per step, photon-sharded over {world} GPU(s)",
-                       "hitpoints": counters["hitpoints"]},
+                                   f"({rounds} rounds x {per_round}), one replica per step (own random streams, camera jittered by 0.00015 as "
+                                   f"Raytracer.h:434), photon-sharded over {world} GPU(s)",
+                       "hitpoints": counters["hitpoints"],
+                       "collective": None if world == 1 else ("gloo over host copies (rehearsal: ranks share GPUs)" if via_host else "rccl all-reduce of the flux image")},
             "photon_pass_mphotons_per_s": per_rank / pass_s / 1e6 if pass_s > 0 else None,
+            "photon_pass_is": "the metric by its own definition (trace + gather of one pass, one iteration in flight); `value` is whole iterations, several in flight",
             "kernel_ms_per_step": {k: v / args.steps for k, v in acc.items()},
             "kernel_ms_per_step_one_in_flight": alone,
             "counters_per_step": {k: (v / args.steps if k != "hitpoints" else v) for k, v in counters.items()},
-            "roofline": {"kernel": "k_gather + k_gather_split (the gather of one photon pass)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
-                         "traffic_source": ("profiles/" + traffic[1] + ": (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc")
-                         if traffic else None,
-                         "bytes_model": "40*candidates + 32*accepted + 64*segments per launch (algorithmic bytes of the "
-                                        "reference's radius search + update loop; the cell-shared sweep re-uses them on chip)",
-                         "algorithmic_bytes_per_launch": bytes_model / max(1, gather_launches),
-                         "avg_launch_ms": alone["gather_ms"] * alone_steps / max(1, gather_launches),
-                         "measured": "HIP events on the library's stream" + (f", {ALONE_STEPS} iterations with one iteration in flight after the "
-                                     "timed region (spans of the timed region include the other streams' kernels), launched as in the "
-                                     "timed region: persistent grids sized to share the GPU with the other contexts' kernels" if len(ctxs) > 1 else
-                                     ", over the timed region")},
+            "device_bytes_all_contexts": footprint,
+            "roofline": roofline, "roofline_gather": roofline_gather,
         }
-        valu = measured_valu(len(ctxs) > 1) if profiled else None
-        if valu:
-            gl = max(1, gather_launches)
-            valu["k_gather_frac_of_valu_peak"] = valu["k_gather_wave_insts"] * 64 / (alone["gather_ms"] * alone_steps / gl / 1e3) / VALU_PEAK_LANE_OPS
-            valu["k_trace_photon_frac_of_valu_peak"] = (valu["k_trace_photon_wave_insts"] * 64 /
-                                                        (alone["photon_trace_ms"] * alone_steps / gl / 1e3) / VALU_PEAK_LANE_OPS)
-            valu["note"] = "wave instructions x 64 lanes / HIP-event duration with one iteration in flight / (256 CU x 4 SIMD x 16 lanes x 2.4 GHz)"
-            out["valu"] = valu
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(scene, w, h, args.cpu_rounds, 4)
+            base = cpu_baseline(scene, w, h, args.cpu_rounds, 4)
+            # the reference's loop is four threads (Raytracer.h:442); beside it the same replicas on every core this job may use
+            cores = max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16)))
+            if cores > 4:
+                allc = cpu_baseline(scene, w, h, max(1, args.cpu_rounds * 4 // cores), cores)
+                base["all_cores"] = {k: allc[k] for k in ("value", "unit", "cores", "sample")}
+            out["cpu_baseline"] = base
         print(json.dumps(out), flush=True)
     for c in ctxs:
         c.close()

@@ -73,12 +73,26 @@ struct Films {
         by_gpu[gpu] = f;
         return f;
     }
-    // fp64 sum over all films, on the host
+    // The sum over all films.  Several GPUs: ONE all-reduce over xGMI (sppm_film_allreduce: RCCL, fp64) leaves it on every
+    // GPU, instead of each film coming back over PCIe to be added on the host (SPPM_FILM_SUM=host keeps that older way,
+    // for a machine without librccl).
+    bool reduce_on_host() const { const char* e = std::getenv("SPPM_FILM_SUM"); return e && std::string(e) == "host"; }
+    std::vector<sppm_film*> all() { std::vector<sppm_film*> v; for (auto& kv : by_gpu) v.push_back(kv.second); return v; }
     std::vector<double> sum() {
-        std::vector<double> total((size_t)w * h * 3, 0.0), part(total.size());
-        for (auto& kv : by_gpu) {
-            check(sppm_film_read(kv.second, part.data()), kv.second, "sppm_film_read");
-            for (size_t e = 0; e < total.size(); e++) total[e] += part[e];
+        std::vector<double> total((size_t)w * h * 3, 0.0);
+        if (by_gpu.empty()) return total;
+        if (by_gpu.size() == 1) {
+            check(sppm_film_read(by_gpu.begin()->second, total.data()), by_gpu.begin()->second, "sppm_film_read");
+        } else if (!reduce_on_host()) {
+            std::vector<sppm_film*> v = all();
+            check(sppm_film_allreduce(v.data(), (int)v.size()), v[0], "sppm_film_allreduce");
+            check(sppm_film_read_total(v[0], total.data()), v[0], "sppm_film_read_total");
+        } else {
+            std::vector<double> part(total.size());
+            for (auto& kv : by_gpu) {
+                check(sppm_film_read(kv.second, part.data()), kv.second, "sppm_film_read");
+                for (size_t e = 0; e < total.size(); e++) total[e] += part[e];
+            }
         }
         return total;
     }
@@ -90,7 +104,13 @@ struct Films {
             check(sppm_film_tonemap(f, n_images, 1, out.data()), f, "sppm_film_tonemap");
             return out;
         }
-        const std::vector<double> total = sum();   // several GPUs: their films meet on the host
+        if (!reduce_on_host()) {                 // several GPUs: their films meet by one all-reduce, tone-mapped where it landed
+            std::vector<sppm_film*> v = all();
+            check(sppm_film_allreduce(v.data(), (int)v.size()), v[0], "sppm_film_allreduce");
+            check(sppm_film_tonemap_total(v[0], n_images, 1, out.data()), v[0], "sppm_film_tonemap_total");
+            return out;
+        }
+        const std::vector<double> total = sum();
         for (int i1 = 0; i1 < h; i1++)
             for (int j = 0; j < w; j++)
                 for (int k = 0; k < 3; k++)

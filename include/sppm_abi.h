@@ -220,6 +220,17 @@ int sppm_film_tonemap(sppm_film* film, double n_images, int rgb, uint8_t* out_hw
 int sppm_film_read(sppm_film* film, double* pic_hw3);
 int sppm_film_write(sppm_film* film, const double* pic_hw3);
 
+/* The image sum of SPPMRayTracer::render (raytracer/Raytracer.h:449-458) when the replicas of an iteration ran on several GPUs
+ * of this process: ONE all-reduce (RCCL, fp64 sum, over xGMI) over n films, one per GPU (distinct devices, equal
+ * resolutions), instead of reading every film back and adding on the host.  Each film keeps its own sum and receives the
+ * sum over all films in a second buffer, which sppm_film_tonemap_total / sppm_film_read_total read (on any of the films:
+ * an all-reduce leaves the total on every GPU).  n = 1 is allowed (the total is then the film's own sum, still through
+ * RCCL).  RCCL is opened at run time (librccl.so.1); SPPM_E_DEVICE if it cannot be.  Waits for the adds queued before the
+ * call.  The communicators are made on first use for a set of GPUs (ncclCommInitAll) and kept for the process. */
+int sppm_film_allreduce(sppm_film* const* films, int n);
+int sppm_film_tonemap_total(sppm_film* film, double n_images, int rgb, uint8_t* out_hw3);
+int sppm_film_read_total(sppm_film* film, double* pic_hw3);
+
 /* sppm_photon_pass, sppm_resolve_device and sppm_film_add only QUEUE their kernels on the context's stream
  * (the reference is synchronous; a GPU host wants to keep queueing).  sppm_synchronize waits
  * for everything queued and returns the error, if any, that a queued pass ran into (a ray /
@@ -256,6 +267,20 @@ void* sppm_get_stream(const sppm_ctx* ctx);
 int sppm_get_hitpoints(sppm_ctx* ctx, sppm_hitpoint* out, uint64_t cap, uint64_t* n);
 int sppm_get_counters(sppm_ctx* ctx, sppm_counters* out);
 int sppm_get_timings(sppm_ctx* ctx, sppm_timings* out);
+
+/* Tallies of the library's own making, over the same span as sppm_counters (no counterpart in the reference; they
+ * depend on how the passes are batched and laid out, which sppm_counters does not):
+ *   stored_deposits  deposit records written for the gather: diffuse photon hits that some HitPoint can reach
+ *   pair_tests       (deposit, HitPoint) pairs the gather evaluated; candidates / pair_tests is its hit rate
+ *   device_bytes     device memory the context holds now (scene tables, HitPoints, grid, deposit buffers, queues)
+ *   deposit_room     deposit slots of the direct-placement layout in use (0: none) */
+typedef struct sppm_device_stats {
+    uint64_t stored_deposits;
+    uint64_t pair_tests;
+    uint64_t device_bytes;
+    uint64_t deposit_room;
+} sppm_device_stats;
+int sppm_get_device_stats(sppm_ctx* ctx, sppm_device_stats* out);
 
 /* Collision record of Scene::NearCollide for the debug entry point below
  * (raytracer/Element.h:20-38).  obj = -1 when nothing was hit. */

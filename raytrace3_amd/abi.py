@@ -78,6 +78,13 @@ class Timings(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class DeviceStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("stored_deposits", "pair_tests", "device_bytes", "deposit_room")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
 class Collision(C.Structure):
     _fields_ = [("pos", C.c_double * 3), ("n", C.c_double * 3), ("color", C.c_double * 3),
                 ("dist", C.c_double), ("obj", C.c_int32), ("inside", C.c_int32)]
@@ -104,6 +111,9 @@ ABI_SYMBOLS = {
     "sppm_film_add": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sppm_film_tonemap": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_void_p]),
     "sppm_film_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "sppm_film_allreduce": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "sppm_film_tonemap_total": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_void_p]),
+    "sppm_film_read_total": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "sppm_film_write": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "sppm_set_radius_update": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint32]),
     "sppm_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -113,6 +123,7 @@ ABI_SYMBOLS = {
     "sppm_get_hitpoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "sppm_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "sppm_get_timings": (C.c_int, [C.c_void_p, C.POINTER(Timings)]),
+    "sppm_get_device_stats": (C.c_int, [C.c_void_p, C.POINTER(DeviceStats)]),
     "sppm_debug_near_collide": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.c_uint64, C.c_uint32, C.c_void_p]),
     "sppm_near_collide_noalloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -252,6 +263,12 @@ class SppmContext:
         self._check(self.lib.sppm_get_counters(self._ctx, C.byref(c)), "sppm_get_counters")
         return c.as_dict()
 
+    def device_stats(self):
+        """The library's own tallies: stored deposits, pair tests of the gather, device bytes held, layout room."""
+        d = DeviceStats()
+        self._check(self.lib.sppm_get_device_stats(self._ctx, C.byref(d)), "sppm_get_device_stats")
+        return d.as_dict()
+
     def timings(self):
         t = Timings()
         self._check(self.lib.sppm_get_timings(self._ctx, C.byref(t)), "sppm_get_timings")
@@ -323,10 +340,22 @@ class Film:
             raise ValueError("film image must be [h][w][3]")
         self._check(self.lib.sppm_film_write(self._film, _dptr(pic)), "sppm_film_write")
 
-    def tonemap(self, n_images, rgb=False):
+    def tonemap(self, n_images, rgb=False, total=False):
+        """total=True: of the sum over GPUs the last allreduce() left in this film."""
         out = np.zeros((self.h, self.w, 3), dtype=np.uint8)
-        self._check(self.lib.sppm_film_tonemap(self._film, float(n_images), int(bool(rgb)), out.ctypes.data_as(C.c_void_p)),
-                    "sppm_film_tonemap")
+        fn, name = ((self.lib.sppm_film_tonemap_total, "sppm_film_tonemap_total") if total else (self.lib.sppm_film_tonemap, "sppm_film_tonemap"))
+        self._check(fn(self._film, float(n_images), int(bool(rgb)), out.ctypes.data_as(C.c_void_p)), name)
+        return out
+
+    @staticmethod
+    def allreduce(films):
+        """One RCCL all-reduce over films on distinct GPUs of this process: each receives the sum of all (read_total())."""
+        arr = (C.c_void_p * len(films))(*[f._film for f in films])
+        films[0]._check(films[0].lib.sppm_film_allreduce(arr, len(films)), "sppm_film_allreduce")
+
+    def read_total(self):
+        out = np.zeros((self.h, self.w, 3), dtype=np.float64)
+        self._check(self.lib.sppm_film_read_total(self._film, _dptr(out)), "sppm_film_read_total")
         return out
 
     def close(self):

@@ -578,7 +578,7 @@ __device__ __forceinline__ void bezier_coop(const SceneView& S, const DevObject&
                 const int pi = first_patch + base + sel;
                 float t, u, v;
                 newton_coop(S.pw_q, S.pw_c, pi, so, sd, ssub, t, u, v);
-                newton_calls += (lane == 0) ? 1u : 0u;
+                newton_calls += 1u;            // wave-uniform tally
                 const float e = (float)SPPM_EPS;
                 // Bezier.h:251-259 (a patch whose minimum-t candidate is negative is dropped as a whole); the
                 // reference walks the patches in index order and keeps the first minimum

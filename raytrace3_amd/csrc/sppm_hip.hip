@@ -16,6 +16,8 @@
 // Several contexts on one GPU (SPPM iterations in flight) launch their persistent grids small enough for a trace
 // workgroup of one and gather workgroups of another to be resident on a CU together (sppm_ctx::trace_blocks_per_cu).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is opened at run time (film_rccl), not linked
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -67,6 +69,8 @@ struct SceneParams {
 
 struct DevCounters {
     unsigned long long photons, segments, deposits, candidates, accepted, newton_calls, eye_segments;
+    unsigned long long stored;       // deposits written for the gather (diffuse hits that some HitPoint can reach)
+    unsigned long long row_tests;    // (HitPoint, row of 64 deposits) sweeps of the gather: x 64 = pairs evaluated
     unsigned long long stamps[8];   // cycle sums per trace-loop section, filled by -DTRACE_STAMPS diagnostic builds only
     unsigned int overflow;   // bit0 hitpoint capacity, bit1 eye task queue, bit2 deposit capacity (sticky: see overflow_code)
     unsigned int pad;
@@ -142,6 +146,11 @@ __device__ __forceinline__ void flush_counter(unsigned long long* dst, uint32_t 
     uint32_t s = wave_sum_u(v);
     if (lane_id() == 0 && s) atomicAdd(dst, (unsigned long long)s);
 }
+// the same for a tally that is wave-uniform already (kept in a scalar register, counted with ballots)
+__device__ __forceinline__ void flush_uniform(unsigned long long* dst, uint32_t v) {
+    if (lane_id() == 0 && v) atomicAdd(dst, (unsigned long long)v);
+}
+__device__ __forceinline__ uint32_t count_lanes(bool p) { return (uint32_t)__popcll(__ballot(p)); }
 
 // ------------------------------------------------------------------ path tracing: eye (pass 1) and photon (pass 2)
 // wave-aggregated allocation of n slots per lane (n may be 0); returns the lane's first slot
@@ -273,7 +282,7 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
     int dep = 0, node = 0;
     Near nr;
     near_init(nr);
-    uint32_t ncalls = 0, nseg = 0, ndep = 0, nphot = 0, nhit = 0;
+    uint32_t ncalls = 0, nseg = 0, ndep = 0, nphot = 0, nhit = 0, nstored = 0;   // wave-uniform tallies (scalar registers): lanes are counted with ballots
     // Work items and deposit slots are claimed from the global counters a chunk at a time (all waves
     // hammering one address with a returned atomic per loop iteration serialises the whole grid).
     unsigned long long work_next = 0, work_end = 0;     // this wave's claimed work items, wave-uniform
@@ -330,6 +339,7 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
             const unsigned long long my = work_next + rank;
             const unsigned long long n = (unsigned long long)__popcll(idle);
             work_next += n < avail ? n : avail;
+            bool took_photon = false;      // this lane starts a freshly emitted photon in this refill
             if (!active && rank < avail) {
                 active = true;
                 pending = false;
@@ -372,10 +382,11 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
                         d = mk(emit_dir[3 * e + 0], emit_dir[3 * e + 1], emit_dir[3 * e + 2]);
                         o = ld3(L.pos);                                                   // Light::emit, Light.h:8-13
                         carry[0] = L.flux[0]; carry[1] = L.flux[1]; carry[2] = L.flux[2];
-                        nphot++;
+                        took_photon = true;
                     }
                 }
             }
+            if (MODE == MODE_PHOTON) nphot += count_lanes(took_photon);
         }
         STAMP(0);
         if (!__any(active)) {
@@ -463,7 +474,7 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
         STAMP(3);
         const Hit hit = finish_hit(S, o, d, fin);
         STAMP(4);
-        if (active) nseg++;
+        nseg += count_lanes(active);
         if (active && hit.obj < 0) active = false;
 
         if (MODE == MODE_EYE) {
@@ -512,8 +523,8 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
                 }
             }
             const unsigned long long hs = chunk_alloc(emit_hp, slot_next, slot_end, tp.n_hits, TRACE_SLOT_CHUNK);
+            nhit += count_lanes(emit_hp);
             if (emit_hp) {
-                nhit++;
                 if (hs < tp.hit_cap) {
                     tp.hits[hs] = rh;
                     atomicAdd(&tp.hcount[key_bucket(cell_key(hit.pos, tp.grid.inv_cs), tp.grid.mask)], 1u);
@@ -567,8 +578,9 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
                 if (dep > SPPM_MAX_DEP) active = false;                                   // Raytracer.h:126-133
             }
             STAMP(6);
-            if (dp) ndep++;
+            ndep += count_lanes(dp);
             dp = dp && keep;
+            nstored += count_lanes(dp);
             if (tp.place) {
                 if (dp) {
                     const uint32_t bk = db.bucket & 0xffffffu;
@@ -603,14 +615,15 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
         tp.wave_chunks[2 * wave_slot] = slot_next;
         tp.wave_chunks[2 * wave_slot + 1] = slot_end;
     }
-    flush_counter(&tp.counters->newton_calls, ncalls);
+    flush_uniform(&tp.counters->newton_calls, ncalls);
     if (MODE == MODE_EYE) {
-        flush_counter(&tp.counters->eye_segments, nseg);
-        flush_counter(tp.n_real_hits, nhit);
+        flush_uniform(&tp.counters->eye_segments, nseg);
+        flush_uniform(tp.n_real_hits, nhit);
     } else {
-        flush_counter(&tp.counters->segments, nseg);
-        flush_counter(&tp.counters->deposits, ndep);
-        flush_counter(&tp.counters->photons, nphot);
+        flush_uniform(&tp.counters->segments, nseg);
+        flush_uniform(&tp.counters->deposits, ndep);
+        flush_uniform(&tp.counters->photons, nphot);
+        flush_uniform(&tp.counters->stored, nstored);
     }
 }
 
@@ -654,7 +667,7 @@ __global__ void __launch_bounds__(256) k_newton(const ParkRec* __restrict__ park
                 pm &= ~(1ull << sel);
                 float t, u, v;
                 newton_coop(pw_q, pw_c, (int)bcast_u(patch, sel), so, sd, sub, t, u, v);
-                done += (lane == 0) ? 1u : 0u;
+                done += 1u;
                 if (lane == sel) { rt = t; ru = u; rv = v; }
                 // what the per-patch filter of Bezier.h:251-259 would accept can lower the bound
                 if (!(t < e || u < -e || u > 1 + e || v < -e || v > 1 + e)) best = fminf(best, t);
@@ -662,7 +675,7 @@ __global__ void __launch_bounds__(256) k_newton(const ParkRec* __restrict__ park
             if (valid) res[first + i] = make_float4(rt, ru, rv, 0.0f);
         }
     }
-    flush_counter(&counters->newton_calls, done);
+    flush_uniform(&counters->newton_calls, done);
 }
 
 // ------------------------------------------------------------------ hashed grid over HitPoints
@@ -867,7 +880,7 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
                                             const Deposit* __restrict__ deps,
                                             const GridParams g, GatherPiece* __restrict__ pieces, unsigned long long* n_pieces,
                                             const uint32_t piece_cap, unsigned int* overflow, const GatherPiece piece,
-                                            uint32_t& cand, uint32_t& acc_n) {
+                                            uint32_t& cand, uint32_t& acc_n, uint32_t& row_tests) {
     const int lane = lane_id();
     const uint32_t mine = base + lane;
     const bool valid = (uint32_t)lane < GATHER_TILE && mine < n_hp;
@@ -964,6 +977,7 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
                 const float wr = bcast_f(mw.x, j), wg = bcast_f(mw.y, j), wb = bcast_f(mw.z, j);
                 float pr = 0, pg = 0, pb = 0;
                 uint32_t pn = 0;
+                row_tests += (uint32_t)rows;
 #pragma unroll
                 for (int r = 0; r < GATHER_ROWS; r++) {
                     if (r < rows) {
@@ -1041,7 +1055,7 @@ __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_po
                                                 unsigned long long* n_pieces, uint32_t piece_cap, DevCounters* counters) {
     const uint32_t n_tiles = (n_hp + GATHER_TILE - 1u) / GATHER_TILE;
     const uint32_t per = (n_tiles + 7u) >> 3;
-    uint32_t cand = 0, acc_n = 0;   // wave-uniform tallies
+    uint32_t cand = 0, acc_n = 0, row_tests = 0;   // wave-uniform tallies
     for (uint32_t s = 0; s < 8; s++) {
         const uint32_t q = (blockIdx.x + s) & 7u;
         const uint32_t q_end = min(n_tiles, (q + 1) * per);
@@ -1051,12 +1065,13 @@ __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_po
             t = bcast_u(t, 0) + q * per;
             if (t >= q_end) break;
             gather_tile<false, FIXED_R2>(t * GATHER_TILE, hp_pos, hp_nr, hp_r2, hp_wgt, hp_tao, n_hp, dstart, dlen, deps, g, pieces, n_pieces, piece_cap,
-                               &counters->overflow, GatherPiece{0, 0, 0, 0}, cand, acc_n);
+                               &counters->overflow, GatherPiece{0, 0, 0, 0}, cand, acc_n, row_tests);
         }
     }
     if (lane_id() == 0) {
         if (cand) atomicAdd(&counters->candidates, (unsigned long long)cand);
         if (acc_n) atomicAdd(&counters->accepted, (unsigned long long)acc_n);
+        if (row_tests) atomicAdd(&counters->row_tests, (unsigned long long)row_tests);
     }
 }
 
@@ -1117,12 +1132,12 @@ __global__ void __launch_bounds__(256) k_gather_split(const PosKey* __restrict__
                                                       const uint32_t* __restrict__ hstart) {
     const unsigned long long n = min(*n_pieces, (unsigned long long)piece_cap);
     const unsigned long long n_waves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
-    uint32_t cand = 0, acc_n = 0;
+    uint32_t cand = 0, acc_n = 0, row_tests = 0;
     // wave w starts with piece w; only when there are more pieces than waves does the shared counter come into
     // play (a launch with nothing queued costs no atomic at all)
     for (unsigned long long i = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n;) {
         const GatherPiece pc = pieces[i];
-        gather_tile<true, FIXED_R2>(pc.tile_base, hp_pos, hp_nr, hp_r2, hp_wgt, hp_tao, n_hp, dstart, dlen, deps, g, nullptr, nullptr, 0u, nullptr, pc, cand, acc_n);
+        gather_tile<true, FIXED_R2>(pc.tile_base, hp_pos, hp_nr, hp_r2, hp_wgt, hp_tao, n_hp, dstart, dlen, deps, g, nullptr, nullptr, 0u, nullptr, pc, cand, acc_n, row_tests);
         if (n <= n_waves) break;
         unsigned long long nx = 0;
         if (lane_id() == 0) nx = atomicAdd(next_piece, 1ull);
@@ -1131,6 +1146,7 @@ __global__ void __launch_bounds__(256) k_gather_split(const PosKey* __restrict__
     if (lane_id() == 0) {
         if (cand) atomicAdd(&counters->candidates, (unsigned long long)cand);
         if (acc_n) atomicAdd(&counters->accepted, (unsigned long long)acc_n);
+        if (row_tests) atomicAdd(&counters->row_tests, (unsigned long long)row_tests);
     }
     if (over) gather_overflow(over, n_over, over_cap, over_max, hstart, hp_pos, hp_nr, hp_r2, hp_wgt, hp_tao, g, counters);
 }
@@ -1226,7 +1242,7 @@ __global__ void __launch_bounds__(256) k_debug_near_collide(SceneParams sp, uint
         c.obj = h.obj; c.inside = h.inside;
         out[i] = c;
     }
-    flush_counter(&counters->newton_calls, ncalls);
+    flush_uniform(&counters->newton_calls, ncalls);
 }
 
 __global__ void __launch_bounds__(256) k_debug_newton(SceneParams sp, uint32_t n, const double* org, const double* dir, const int* patch,
@@ -2287,6 +2303,30 @@ int sppm_get_counters(sppm_ctx* ctx, sppm_counters* out) {
     return SPPM_OK;
 }
 
+int sppm_get_device_stats(sppm_ctx* ctx, sppm_device_stats* out) {
+    if (!ctx || !out) return SPPM_E_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    DevCounters dc;
+    HIPCHK(hipMemcpyAsync(&dc, ctx->counters.p, sizeof(dc), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    out->stored_deposits = dc.stored;
+    out->pair_tests = dc.row_tests * 64ull;
+    out->deposit_room = ctx->place_valid ? ctx->place_total : 0;
+    size_t b = 0;
+    auto add = [&](size_t n, size_t elem) { b += n * elem; };
+    add(ctx->blob.n, 1); add(ctx->texels.n, sizeof(uchar4)); add(ctx->pw_q.n, sizeof(float)); add(ctx->pw_c.n, sizeof(double));
+    add(ctx->sub_box.n, sizeof(float)); add(ctx->lights.n, sizeof(DevLight)); add(ctx->raw.n, sizeof(RawHit));
+    for (int k = 0; k < 2; k++) { add(ctx->park[k].n, sizeof(ParkRec)); add(ctx->ntask[k].n, sizeof(NewtonTask)); }
+    add(ctx->nres.n, sizeof(float4)); add(ctx->hstart.n, 4); add(ctx->hist.n, 4);
+    add(ctx->hp_pos.n, sizeof(PosKey)); add(ctx->hp_nr.n, sizeof(float4)); add(ctx->hp_wgt.n, sizeof(float4)); add(ctx->hp_tao.n, sizeof(float4));
+    add(ctx->hp_meta.n, sizeof(HpMeta)); add(ctx->hp_r2.n, sizeof(double));
+    add(ctx->dep.n, sizeof(Deposit)); add(ctx->sdep.n, sizeof(Deposit)); add(ctx->pieces.n, sizeof(GatherPiece));
+    add(ctx->place_room.n, 4); add(ctx->place_start.n, 4); add(ctx->place_over_max.n, 8); add(ctx->dstart.n, 4); add(ctx->scan_partial.n, 4);
+    add(ctx->ctl.n, 8); add(ctx->counters.n, sizeof(DevCounters)); add(ctx->pic.n, sizeof(float));
+    out->device_bytes = b;
+    return SPPM_OK;
+}
+
 // Waits for the stream and sums the spans recorded since the last sppm_eye_pass call.
 int sppm_get_timings(sppm_ctx* ctx, sppm_timings* out) {
     if (!ctx || !out) return SPPM_E_INVALID;
@@ -2462,6 +2502,8 @@ struct sppm_film {
     int device = 0, w = 0, h = 0;
     hipStream_t stream = nullptr;
     DevBuf<double> acc;
+    DevBuf<double> total;                       // sum over the films of all GPUs, left here by sppm_film_allreduce
+    bool have_total = false;
     DevBuf<uint8_t> bytes;
     DevBuf<uint32_t> flagged;
     std::mutex mu;                              // contexts add from their own host threads
@@ -2517,7 +2559,7 @@ void sppm_film_destroy(sppm_film* film) {
     (void)hipSetDevice(film->device);
     for (auto& kv : film->last_add) { (void)hipEventSynchronize(kv.second); (void)hipEventDestroy(kv.second); }
     (void)hipStreamSynchronize(film->stream);
-    film->acc.release(); film->bytes.release(); film->flagged.release();
+    film->acc.release(); film->bytes.release(); film->flagged.release(); film->total.release();
     (void)hipStreamDestroy(film->stream);
     delete film;
 }
@@ -2585,15 +2627,11 @@ int sppm_film_write(sppm_film* film, const double* pic_hw3) {
     return SPPM_OK;
 }
 
-int sppm_film_tonemap(sppm_film* film, double n_images, int rgb, uint8_t* out_hw3) {
-    if (!film || !out_hw3) return SPPM_E_INVALID;
-    if (!(n_images > 0)) return film_fail(film, SPPM_E_INVALID, "n_images must be positive");
-    std::lock_guard<std::mutex> g(film->mu);
-    FILMCHK(hipSetDevice(film->device));
-    if (int rc = film_join(film)) return rc;
+// toInt of src / n_images (src: the film's own sum or the total over GPUs), see sppm_film_tonemap
+static int film_tonemap_from(sppm_film* film, const double* src, double n_images, int rgb, uint8_t* out_hw3) {
     const size_t n = film->elems();
     hipLaunchKernelGGL(k_fill_u32, dim3(1), dim3(64), 0, film->stream, film->flagged.p, (size_t)1, 0u);
-    hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, film->stream, film->acc.p, film->w, film->h, n_images, rgb,
+    hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, film->stream, src, film->w, film->h, n_images, rgb,
                        film->bytes.p, film->flagged.p, FILM_FLAG_CAP);
     FILMCHK(hipGetLastError());
     uint32_t n_flagged = 0;
@@ -2613,15 +2651,123 @@ int sppm_film_tonemap(sppm_film* film, double n_images, int rgb, uint8_t* out_hw
         FILMCHK(hipMemcpy(idx.data(), film->flagged.p + 1, n_flagged * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (uint32_t e : idx) {
             double x = 0;
-            FILMCHK(hipMemcpy(&x, film->acc.p + e, sizeof(double), hipMemcpyDeviceToHost));
+            FILMCHK(hipMemcpy(&x, src + e, sizeof(double), hipMemcpyDeviceToHost));
             out_hw3[at(e)] = host_to_int(x / n_images);
         }
     } else {
         std::vector<double> all(n);
-        FILMCHK(hipMemcpy(all.data(), film->acc.p, n * sizeof(double), hipMemcpyDeviceToHost));
+        FILMCHK(hipMemcpy(all.data(), src, n * sizeof(double), hipMemcpyDeviceToHost));
         for (size_t e = 0; e < n; e++) out_hw3[at(e)] = host_to_int(all[e] / n_images);
     }
     return SPPM_OK;
 }
 
+int sppm_film_tonemap(sppm_film* film, double n_images, int rgb, uint8_t* out_hw3) {
+    if (!film || !out_hw3) return SPPM_E_INVALID;
+    if (!(n_images > 0)) return film_fail(film, SPPM_E_INVALID, "n_images must be positive");
+    std::lock_guard<std::mutex> g(film->mu);
+    FILMCHK(hipSetDevice(film->device));
+    if (int rc = film_join(film)) return rc;
+    return film_tonemap_from(film, film->acc.p, n_images, rgb, out_hw3);
+}
+
+int sppm_film_tonemap_total(sppm_film* film, double n_images, int rgb, uint8_t* out_hw3) {
+    if (!film || !out_hw3) return SPPM_E_INVALID;
+    if (!(n_images > 0)) return film_fail(film, SPPM_E_INVALID, "n_images must be positive");
+    std::lock_guard<std::mutex> g(film->mu);
+    if (!film->have_total) return film_fail(film, SPPM_E_INVALID, "sppm_film_allreduce must come first");
+    FILMCHK(hipSetDevice(film->device));
+    return film_tonemap_from(film, film->total.p, n_images, rgb, out_hw3);
+}
+
+int sppm_film_read_total(sppm_film* film, double* pic_hw3) {
+    if (!film || !pic_hw3) return SPPM_E_INVALID;
+    std::lock_guard<std::mutex> g(film->mu);
+    if (!film->have_total) return film_fail(film, SPPM_E_INVALID, "sppm_film_allreduce must come first");
+    FILMCHK(hipSetDevice(film->device));
+    FILMCHK(hipMemcpyAsync(pic_hw3, film->total.p, film->elems() * sizeof(double), hipMemcpyDeviceToHost, film->stream));
+    FILMCHK(hipStreamSynchronize(film->stream));
+    return SPPM_OK;
+}
+
 }  // extern "C"
+
+// ------------------------------------------------------------------ film sum over the GPUs of one process (RCCL over xGMI)
+// The serial image sum of Raytracer.h:449-458 when the replicas ran on several GPUs: one all-reduce (fp64 sum) over the
+// films, one per GPU.  RCCL is opened at run time: a copy the process already holds (a host that has loaded PyTorch has
+// PyTorch's) is taken first, so that no second ROCm runtime comes in; otherwise librccl.so.1 from the library path.
+namespace {
+struct FilmRccl {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+    std::map<std::vector<int>, std::vector<ncclComm_t>> comms;     // one communicator set per list of devices, kept for the process
+    std::mutex mu;
+    bool open() {
+        if (lib) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so"}) if ((lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD))) break;
+        if (!lib) for (const char* name : {"librccl.so.1", "librccl.so"}) if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!lib) { err = std::string("cannot open librccl: ") + dlerror(); return false; }
+        CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+        GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !AllReduce || !GroupStart || !GroupEnd || !GetErrorString) {
+            err = "librccl lacks an expected symbol"; lib = nullptr; return false;
+        }
+        return true;
+    }
+};
+FilmRccl& film_rccl() { static FilmRccl r; return r; }
+}  // namespace
+
+extern "C" int sppm_film_allreduce(sppm_film* const* films, int n) {
+    if (!films || n <= 0 || n > 64) return SPPM_E_INVALID;
+    sppm_film* first = films[0];
+    if (!first) return SPPM_E_INVALID;
+    std::vector<int> devs;
+    for (int i = 0; i < n; i++) {
+        if (!films[i]) return SPPM_E_INVALID;
+        if (films[i]->w != first->w || films[i]->h != first->h) return film_fail(first, SPPM_E_INVALID, "films of different resolutions");
+        for (int d : devs) if (d == films[i]->device) return film_fail(first, SPPM_E_INVALID, "two films on one GPU: one film per GPU takes part in the sum");
+        devs.push_back(films[i]->device);
+    }
+    FilmRccl& r = film_rccl();
+    std::lock_guard<std::mutex> g(r.mu);
+    if (!r.open()) return film_fail(first, SPPM_E_DEVICE, r.err);
+    auto it = r.comms.find(devs);
+    if (it == r.comms.end()) {
+        std::vector<ncclComm_t> c((size_t)n);
+        ncclResult_t rc = r.CommInitAll(c.data(), n, devs.data());
+        if (rc != ncclSuccess) return film_fail(first, SPPM_E_DEVICE, std::string("ncclCommInitAll: ") + r.GetErrorString(rc));
+        it = r.comms.emplace(devs, c).first;
+    }
+    const size_t count = first->elems();
+    for (int i = 0; i < n; i++) {            // each film's stream waits for the adds queued on it so far
+        sppm_film* film = films[i];
+        std::lock_guard<std::mutex> fg(film->mu);
+        FILMCHK(hipSetDevice(film->device));
+        FILMCHK(film->total.reserve(count));
+        if (int rc = film_join(film)) return rc;
+    }
+    ncclResult_t rc = r.GroupStart();
+    for (int i = 0; i < n && rc == ncclSuccess; i++)
+        rc = r.AllReduce(films[i]->acc.p, films[i]->total.p, count, ncclDouble, ncclSum, it->second[(size_t)i], films[i]->stream);
+    const ncclResult_t rc_end = r.GroupEnd();
+    if (rc == ncclSuccess) rc = rc_end;
+    if (rc != ncclSuccess) return film_fail(first, SPPM_E_DEVICE, std::string("ncclAllReduce: ") + r.GetErrorString(rc));
+    for (int i = 0; i < n; i++) {
+        sppm_film* film = films[i];
+        FILMCHK(hipSetDevice(film->device));
+        FILMCHK(hipStreamSynchronize(film->stream));
+        film->have_total = true;
+    }
+    return SPPM_OK;
+}

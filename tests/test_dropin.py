@@ -51,13 +51,17 @@ def test_cpp_host_matches_python_host_and_oracle(tmp_path):
     g.close()
     assert cpp.mean() > 0
     assert np.allclose(cpp, py, rtol=1e-4, atol=1e-6 * py.mean())
-    o = ol.OracleContext()
-    o.set_scene(scene)
-    o.eye_pass(cam, 77, replica=3)
-    o.photon_pass(60, 100, 77, replica=3)
-    c = o.resolve()
-    diff = np.abs(cpp - c).max(axis=2) / c.mean()
-    assert (diff <= 1e-3).mean() >= 0.97 and diff.mean() <= 2e-3
+    # the stated tolerance (image relative to its mean: within 1e-3 on >= 99.5 % of the pixels, mean abs error <= 1e-4),
+    # against the oracle with Newton in fp32 as the tolerance is defined, and against the all-fp64 oracle beside it
+    for fp32 in (True, False):
+        o = ol.OracleContext(newton_fp32=fp32)
+        o.set_scene(scene)
+        o.eye_pass(cam, 77, replica=3)
+        o.photon_pass(60, 100, 77, replica=3)
+        c = o.resolve()
+        diff = np.abs(cpp - c).max(axis=2) / c.mean()
+        print(f"newton_fp32={fp32}: within 1e-3 {(diff <= 1e-3).mean():.5f}, outliers {int((diff > 1e-3).sum())}, MAE {diff.mean():.2e}")
+        assert (diff <= 1e-3).mean() >= 0.995 and diff.mean() <= 1e-4
 
 
 def _read_ppm(path):
@@ -168,13 +172,15 @@ def test_stock_scene_with_ppm_textures(tmp_path):
     g.close()
     assert cpp.mean() > 0
     assert np.allclose(cpp, py, rtol=1e-4, atol=1e-6 * py.mean())
-    o = ol.OracleContext()
-    o.set_scene(scene)
-    o.eye_pass(cam, 78, replica=1)
-    o.photon_pass(60, 100, 78, replica=1)
-    c = o.resolve()
-    diff = np.abs(cpp - c).max(axis=2) / c.mean()
-    assert (diff <= 1e-3).mean() >= 0.97 and diff.mean() <= 2e-3
+    for fp32 in (True, False):
+        o = ol.OracleContext(newton_fp32=fp32)
+        o.set_scene(scene)
+        o.eye_pass(cam, 78, replica=1)
+        o.photon_pass(60, 100, 78, replica=1)
+        c = o.resolve()
+        diff = np.abs(cpp - c).max(axis=2) / c.mean()
+        print(f"newton_fp32={fp32}: within 1e-3 {(diff <= 1e-3).mean():.5f}, outliers {int((diff > 1e-3).sum())}, MAE {diff.mean():.2e}")
+        assert (diff <= 1e-3).mean() >= 0.995 and diff.mean() <= 1e-4
     # the textures matter: the same scene with the stand-ins gives another picture
     assert not np.allclose(c, _oracle_image(scenes.scene_teapot(1), cam, 78, 1), rtol=1e-2, atol=1e-3 * c.mean())
 

@@ -7,8 +7,9 @@ Each configuration of BASELINE.json is checked twice:
   * at its full size on the GPU alone through properties that do not need the oracle: the photon
     count, sum(newN) == accepted updates, additivity over photon shards (what multi-GPU sharding
     relies on) and independence of the batch size.
-Tolerances are those of tests/test_gpu_parity.py (flux image relative to its mean: |diff| <= 1e-3 on
->= 99.5 % of pixels, analytic scenes; 97 % where Bezier Newton results differ at the fp32 scale).
+Tolerances are those of tests/test_gpu_parity.py: flux image relative to its mean, |diff| <= 1e-3 on >= 99.5 % of the
+pixels and mean abs error <= 1e-4 for EVERY scene, Bezier ones included, against the oracle with Newton in fp32 (what the
+tolerance is defined against) and against the all-fp64 oracle; >= 99 % of Bezier HitPoints within 1e-3 of the oracle's.
 """
 import os
 
@@ -30,8 +31,8 @@ def gpu():
     ctx.close()
 
 
-def _oracle(scene):
-    o = ol.OracleContext()
+def _oracle(scene, newton_fp32=False):
+    o = ol.OracleContext(newton_fp32=newton_fp32)
     o.set_scene(scene)
     return o
 
@@ -51,30 +52,66 @@ def _analytic_positions(g, c):
     """Plane / sphere HitPoints, fp64 on both sides.  Seen directly (tree node 0) they agree to 1e-9; behind a
     mirror or glass sphere the last-bit differences of the two arithmetics (FMA contraction on the GPU) are
     magnified by the curved surface (distance / radius per bounce) and by the distance travelled: 1e-10
-    relative + 1e-7 absolute (measured worst case 4.5e-8 at z = 1482 behind the mirror ball)."""
+    relative + 1e-7 absolute (measured worst case 4.5e-8 at z = 1482 behind the mirror ball).  Normals are the
+    same fp64 values stored as fp32: 1e-7 (measured 3e-8)."""
     direct = c["node"] == 0
     assert np.allclose(g["pos"][direct], c["pos"][direct], rtol=1e-12, atol=1e-9)
     assert np.allclose(g["pos"][~direct], c["pos"][~direct], rtol=1e-10, atol=1e-7)
+    assert np.allclose(g["n"], c["n"], rtol=0, atol=1e-7)
 
 
-def _image_parity(g, c, frac, linf=1e-3, mae=1e-4):
+def _image_parity(g, c, frac=0.995, linf=1e-3, mae=1e-4):
     mean = c.mean()
     assert mean > 0
     diff = np.abs(g - c).max(axis=2) / mean
     good = (diff <= linf).mean()
-    print(f"image parity: within {linf:g}: {good:.5f}, MAE/mean {diff.mean():.3g}, max {diff.max():.3g}")
+    print(f"image parity: within {linf:g}: {good:.5f}, outliers {int((diff > linf).sum())} of {diff.size}, MAE/mean {diff.mean():.3g}, max {diff.max():.3g}")
     assert good >= frac, good
     assert diff.mean() <= mae, diff.mean()
 
 
-def _run_pair(gpu, scene, cam, rounds, per_round, count):
+def _bezier_hitpoints(g, c, first_bezier_obj, frac=0.99):
+    """GPU and oracle HitPoints of a Bezier scene: the same (pixel, node) set and objects but for a few silhouette rays,
+    analytic ones to the analytic tolerances, >= frac of the Bezier ones within 1e-3 (measured 99.2-99.4 % against the
+    fp32-Newton oracle, 99.7-99.9 % against the fp64 one), Bezier normals to 1e-5 at the median."""
+    gm, cm, n_common = _match(g, c)
+    assert n_common >= 0.9995 * len(c) and abs(len(g) - len(c)) <= 5e-4 * len(c), (len(g), len(c), n_common)
+    same = gm["obj"] == cm["obj"]
+    assert same.mean() >= 0.9995
+    bez = cm["obj"] >= first_bezier_obj
+    _analytic_positions(gm[same & ~bez], cm[same & ~bez])
+    perr = np.abs(gm["pos"] - cm["pos"]).max(axis=1)[same & bez]
+    nerr = np.abs(gm["n"] - cm["n"]).max(axis=1)[same & bez]
+    print(f"Bezier HitPoints: {perr.size}, within 1e-3: {(perr <= 1e-3).mean():.5f}, median {np.median(perr):.2e}, max {perr.max():.2e}; "
+          f"normals median {np.median(nerr):.2e}, max {nerr.max():.2e}")
+    assert perr.size > 0 and (perr <= 1e-3).mean() >= frac, (perr <= 1e-3).mean()
+    assert np.median(nerr) <= 1e-5 and (nerr <= 1e-3).mean() >= 0.98 and nerr.max() <= 0.1
+
+
+def _run_pair(gpu, scene, cam, rounds, per_round, count, newton_fp32=False):
     gpu.set_scene(scene)
     gpu.eye_pass(cam, SEED)
     gpu.photon_pass(rounds, per_round, SEED, photon_begin=0, photon_count=count)
-    o = _oracle(scene)
+    o = _oracle(scene, newton_fp32)
     o.eye_pass(cam, SEED)
     o.photon_pass(rounds, per_round, SEED, photon_begin=0, photon_count=count)
     return o
+
+
+def _bezier_case(gpu, scene, cam, rounds, per_round, count, first_bezier_obj=8):
+    """One Bezier scene through both passes against the fp32-Newton oracle (the stated tolerance) and the fp64 one (the
+    floor): HitPoints, tallies, image."""
+    for fp32 in (True, False):
+        o = _run_pair(gpu, scene, cam, rounds, per_round, count, newton_fp32=fp32)
+        _bezier_hitpoints(gpu.hitpoints(), o.hitpoints(), first_bezier_obj)
+        cg, co = gpu.counters(), o.counters()
+        assert cg["photons"] == co["photons"]
+        for k in ("segments", "deposits", "candidates", "accepted", "eye_segments"):      # measured: within 5e-5
+            assert cg[k] == pytest.approx(co[k], rel=1e-3), k
+        # nearest-box-first solves that skip boxes which cannot hold a nearer hit: fewer solves for the same hits
+        assert 0.1 * co["newton_calls"] <= cg["newton_calls"] <= co["newton_calls"]
+        _image_parity(gpu.resolve(), o.resolve())
+        o.close()
 
 
 def _gpu_properties(gpu, rounds, per_round, n_lights=1, halves=True):
@@ -117,22 +154,52 @@ def test_c1_full_size_against_oracle(gpu):
 
 
 # ------------------------------------------------------------------ config 2: teapot scene, 800 x 600, 1 M photons
-def test_c2_full_size_eye_pass_and_photon_slice_against_oracle(gpu):
+def test_c2_full_size_against_oracle(gpu):
+    """The whole of config 2 — all 480 000 pixels and all 1 M photons — against both oracles (8 s of CPU each)."""
     factory, (w, h), rounds, per_round = scenes.CONFIGS["c2_teapot_800x600"]
+    _bezier_case(gpu, factory(), scenes.default_camera(w, h), rounds, per_round, 0)
+
+
+# ------------------------------------------------------------------ config 3: the same scene, 10 M photons over 8 GPUs
+def test_c3_workload_as_eight_photon_shards(gpu):
+    """Config 3 is config 2 with 10 M photons per iteration, photon-sharded over 8 GPUs whose flux images one all-reduce
+    sums.  Its workload on one GPU: the 8 shards photon_shard(10 M, g, 8), each resolved with the normaliser of the whole
+    pass and summed (what the all-reduce does), equal the single 10 M-photon pass up to the order of the fp32 sums; the
+    first 250 k photons of the pass (a fifth of shard 0) agree with the oracle's."""
+    from raytrace3_amd.distributed import photon_shard
+    factory, (w, h), rounds, per_round = scenes.CONFIGS["c3_teapot_800x600_10M"]
+    assert rounds * per_round == 10_000_000
     scene, cam = factory(), scenes.default_camera(w, h)
-    o = _run_pair(gpu, scene, cam, rounds, per_round, 50_000)
-    g, c = gpu.hitpoints(), o.hitpoints()
-    gm, cm, n_common = _match(g, c)
-    # Bezier silhouettes: a Newton solve that converges in one arithmetic and not in the other moves a HitPoint
-    assert n_common >= 0.999 * len(c) and abs(len(g) - len(c)) <= 1e-3 * len(c), (len(g), len(c), n_common)
-    same = gm["obj"] == cm["obj"]
-    assert same.mean() >= 0.999
-    perr = np.abs(gm["pos"] - cm["pos"]).max(axis=1)[same]
-    analytic = cm["obj"][same] != 8
-    _analytic_positions(gm[same][analytic], cm[same][analytic])
-    assert (perr[~analytic] <= 1e-3).mean() >= 0.97
-    assert gpu.counters()["eye_segments"] == pytest.approx(o.counters()["eye_segments"], rel=1e-4)
-    _image_parity(gpu.resolve(), o.resolve(), frac=0.97, mae=2e-3)
+    gpu.set_scene(scene)
+    gpu.eye_pass(cam, SEED)
+    gpu.photon_pass(rounds, per_round, SEED)
+    c_full, full = gpu.counters(), gpu.resolve()
+    assert c_full["photons"] == 10_000_000
+    total_img = np.zeros_like(full)
+    tallies = dict.fromkeys(("photons", "segments", "deposits", "candidates", "accepted"), 0)
+    for g in range(8):
+        begin, count = photon_shard(rounds * per_round, g, 8)
+        assert count == 1_250_000
+        gpu.eye_pass(cam, SEED)                          # every rank runs the eye pass itself
+        gpu.photon_pass(rounds, per_round, SEED, photon_begin=begin, photon_count=count)
+        gpu.resolve(accumulate_into=total_img)
+        c = gpu.counters()
+        for k in tallies:
+            tallies[k] += c[k]
+    assert all(tallies[k] == c_full[k] for k in tallies), (tallies, c_full)          # the same photons, the same pairs
+    assert np.allclose(total_img, full, rtol=2e-4, atol=1e-6 * full.mean())
+    # an oracle slice of the 10 M pass: its first 250 000 photons, resolved with the whole pass's normaliser
+    n_slice = 250_000
+    gpu.eye_pass(cam, SEED)
+    gpu.photon_pass(rounds, per_round, SEED, photon_begin=0, photon_count=n_slice)
+    o = _oracle(scene, newton_fp32=True)
+    o.eye_pass(cam, SEED)
+    o.photon_pass(rounds, per_round, SEED, photon_begin=0, photon_count=n_slice)
+    cg, co = gpu.counters(), o.counters()
+    assert cg["photons"] == co["photons"] == n_slice
+    for k in ("segments", "deposits", "candidates", "accepted"):
+        assert cg[k] == pytest.approx(co[k], rel=1e-3), k
+    _image_parity(gpu.resolve(), o.resolve())
 
 
 def test_c2_full_size_properties(gpu):
@@ -144,19 +211,10 @@ def test_c2_full_size_properties(gpu):
 
 
 # ------------------------------------------------------------------ config 4: four teapots (128 patches), 1920 x 1080
-def test_c4_reduced_against_oracle(gpu):
-    scene, cam = scenes.scene_teapot(4), scenes.default_camera(480, 270)
-    o = _run_pair(gpu, scene, cam, 10000, 100, 20_000)
-    g, c = gpu.hitpoints(), o.hitpoints()
-    gm, cm, n_common = _match(g, c)
-    assert n_common >= 0.995 * len(c)
-    same = gm["obj"] == cm["obj"]
-    assert same.mean() >= 0.995
-    perr = np.abs(gm["pos"] - cm["pos"]).max(axis=1)[same]
-    assert (perr <= 1e-3).mean() >= 0.97
-    # nearest-box-first with skipping of boxes that cannot hold a nearer hit: fewer solves, same hits
-    assert 0.2 * o.counters()["newton_calls"] <= gpu.counters()["newton_calls"] <= o.counters()["newton_calls"]
-    _image_parity(gpu.resolve(), o.resolve(), frac=0.95, mae=4e-3)
+def test_c4_quarter_size_against_oracle(gpu):
+    """Config 4 at half its resolution in each direction (960 x 540, 518 k HitPoints of which 24 k on the teapots) and a
+    tenth of its photons."""
+    _bezier_case(gpu, scenes.scene_teapot(4), scenes.default_camera(960, 540), 10000, 100, 100_000)
 
 
 def test_c4_full_size_properties(gpu):
@@ -181,18 +239,11 @@ def test_large_scenes(gpu, extra):
     """Seven teapots = 224 patches: the staged scene tables take 58 KiB of LDS and the photon kernel adds 12 KiB of
     emission slices, the largest workgroup footprint there is.  Ten teapots = 320 patches: the tables (82 KiB) no longer
     fit the staging area and are read from global memory, and rays are never parked (a parked ray names its patches in
-    a 256-bit mask).  Both passes against the oracle, at the tolerances of the Bezier tests."""
+    a 256-bit mask).  Both passes against both oracles, at the stated tolerances."""
     scene, cam = _room_with_teapots(extra), scenes.default_camera(240, 135)
     assert scene.patches.shape[0] == 32 * (4 + extra)
-    o = _run_pair(gpu, scene, cam, 10000, 100, 10_000)
-    g, c = gpu.hitpoints(), o.hitpoints()
-    gm, cm, n_common = _match(g, c)
-    assert n_common >= 0.995 * len(c)
-    same = gm["obj"] == cm["obj"]
-    assert same.mean() >= 0.995
-    assert (np.abs(gm["pos"] - cm["pos"]).max(axis=1)[same] <= 1e-3).mean() >= 0.97
-    assert gpu.counters()["photons"] == o.counters()["photons"] == 10_000
-    _image_parity(gpu.resolve(), o.resolve(), frac=0.95, mae=4e-3)
+    _bezier_case(gpu, scene, cam, 10000, 100, 10_000)
+    o = _oracle(scene)
     # the parity hooks take the same route to the tables
     rng = np.random.default_rng(3)
     org = np.tile([50., 35., 230.], (2048, 1))

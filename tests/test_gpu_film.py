@@ -161,3 +161,36 @@ def test_five_contexts_in_flight_add_up_like_one():
         one.close()
     assert alone.sum() > 0
     assert np.allclose(together, alone, rtol=2e-4, atol=1e-6 * alone.mean())
+
+
+def test_film_allreduce_through_rccl_with_the_one_rank_this_box_has():
+    """sppm_film_allreduce sums the films of several GPUs with one RCCL all-reduce (fp64) instead of on the host.  On a
+    one-GPU box the communicator has one rank: the path through librccl (opened at run time, ncclCommInitAll,
+    ncclAllReduce on the film's stream, ordered after the adds queued on it) runs for real and the total must be the film's
+    own sum, which stays untouched; tone-mapping the total gives the bytes of tone-mapping the film.  More than one rank is
+    unmeasured here (no box with two GPUs)."""
+    scene, cam = scenes.scene_teapot(1), scenes.default_camera(W, H)
+    g = SppmContext(0)
+    film, other = Film(W, H), Film(W, H)
+    try:
+        g.set_scene(scene)
+        with pytest.raises(SppmError, match="sppm_film_allreduce must come first"):
+            film.read_total()
+        for replica in range(2):
+            g.eye_pass(cam, SEED, replica)
+            g.photon_pass(40, 100, SEED, replica)
+            film.add(g)
+            Film.allreduce([film])                    # queued behind the add, no host wait in between
+            own = film.read()
+            assert own.sum() > 0 and np.array_equal(film.read_total(), own)
+        for rgb in (False, True):
+            assert np.array_equal(film.tonemap(2.0, rgb=rgb, total=True), film.tonemap(2.0, rgb=rgb))
+        # the film's own sum keeps accumulating after a reduction (the total is a second buffer)
+        g.eye_pass(cam, SEED, 2)
+        g.photon_pass(40, 100, SEED, 2)
+        film.add(g)
+        assert film.read().sum() > own.sum() and np.array_equal(film.read_total(), own)
+        with pytest.raises(SppmError, match="two films on one GPU"):
+            Film.allreduce([film, other])
+    finally:
+        film.close(); other.close(); g.close()

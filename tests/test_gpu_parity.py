@@ -2,14 +2,19 @@
 same seeded inputs.
 
 Tolerances.  The device computes ray state / analytic hits / gather distances in fp64
-and the Bezier Newton solve, colours and accumulators in fp32; the oracle is all fp64
-(optionally fp32 inside Newton).  So:
-  * analytic (plane / sphere) geometry: 1e-9 absolute on positions and distances;
+and the Bezier Newton solve, colours and accumulators in fp32; the oracle is all fp64,
+optionally with fp32 inside Newton (`newton_fp32=True`), which is what the stated image
+tolerance is defined against.  So:
+  * analytic (plane / sphere) geometry: 1e-9 absolute on positions and distances, normals
+    to 1e-7 (they are stored as fp32);
   * Bezier hits: the Newton result is the minimum-t iterate with residual < 1e-2, so two
-    arithmetic types agree to ~1e-4 on most rays and differ by up to the residual
-    threshold on the few rays where a different iterate wins; stated per test;
-  * flux image: relative to the image mean, |diff| <= 1e-3 on >= 99.5 % of pixels and
-    mean-abs-error <= 1e-4 (fp32 accumulation order + discrete-decision flips).
+    arithmetics agree to ~1e-5 on most rays (measured median 7e-6 against the fp32 oracle,
+    2e-6 against the fp64 one: the device's power-basis form around the patch centre is
+    the more accurate fp32 evaluation) and differ by up to the residual threshold on the
+    few rays where a different iterate wins: >= 99 % of Bezier HitPoints within 1e-3;
+  * flux image, every scene: relative to the image mean, |diff| <= 1e-3 on >= 99.5 % of
+    pixels and mean-abs-error <= 1e-4, against BOTH oracles (outlier count printed).
+The measured values behind these numbers come from tools/parity_report.py.
 """
 import numpy as np
 import pytest
@@ -146,16 +151,17 @@ def test_newton_golden_cases(gpu):
     c64 = _oracle(scene).newton(org, d, patch, SEED)
     found_c, found_g = c64[:, 0] < 1e19, g[:, 0] < 1e19
     assert found_c.sum() > 60
-    # converged / not converged decisions agree on all but a few borderline cases
-    assert (found_c != found_g).sum() <= 3
-    both = found_c & found_g
-    err = np.abs(g[both] - c64[both]).max(axis=1)
-    assert np.median(err) < 1e-4
-    assert (err < 1e-3).mean() > 0.9, (err < 1e-3).mean()
-    assert err.max() < 0.05          # never further apart than the residual threshold allows
-    both32 = (c32[:, 0] < 1e19) & found_g
-    err32 = np.abs(g[both32] - c32[both32]).max(axis=1)
-    assert np.median(err32) < 1e-4
+    # converged / not converged decisions agree (measured: on all 256; one borderline case is allowed)
+    assert (found_c != found_g).sum() <= 1 and ((c32[:, 0] < 1e19) != found_g).sum() <= 1
+    # measured: median 3.9e-6 / 1.3e-5, within 1e-3 98.3 % / 97.9 %, worst 6.4e-3 / 9.8e-3 (fp64 / fp32 oracle): the few
+    # cases beyond 1e-3 are rays where another iterate of the same restart passes the residual test first
+    for name, c in (("fp64", c64), ("fp32", c32)):
+        both = (c[:, 0] < 1e19) & found_g
+        err = np.abs(g[both] - c[both]).max(axis=1)
+        print(f"newton vs {name} oracle: {both.sum()} cases, median {np.median(err):.2e}, within 1e-3 {(err < 1e-3).mean():.4f}, max {err.max():.2e}")
+        assert np.median(err) < 3e-5
+        assert (err < 1e-3).mean() >= 0.96, (err < 1e-3).mean()
+        assert err.max() < 0.02          # never further apart than the residual threshold (0.01 in space) allows
 
 
 def test_bezier_nearest_hit_over_many_patches(gpu):
@@ -210,7 +216,9 @@ def test_axis_parallel_rays_through_the_teapot(gpu):
     assert np.median(derr) < 1e-4 and (derr < 1e-3).mean() >= 0.97 and derr.max() < 0.05
 
 
-def _compare_hitpoints(g, c, pos_tol, frac, bezier_objs=()):
+def _compare_hitpoints(g, c, pos_tol, frac, bezier_objs=(), bezier_frac=0.99, slack=0):
+    """frac: share of all HitPoints that must agree within pos_tol; bezier_frac: the same among the Bezier ones alone
+    (slack: that many of them may miss it whatever the share, for samples of a few dozen)."""
     assert len(g) > 0
     kg, kc = _key(g), _key(c)
     og, oc = np.argsort(kg), np.argsort(kc)
@@ -221,16 +229,26 @@ def _compare_hitpoints(g, c, pos_tol, frac, bezier_objs=()):
     g, c = g[ig], c[ic]
     same_obj = g["obj"] == c["obj"]
     assert same_obj.mean() >= frac
-    perr = np.abs(g["pos"] - c["pos"]).max(axis=1)[same_obj]
+    perr_all = np.abs(g["pos"] - c["pos"]).max(axis=1)
+    perr = perr_all[same_obj]
     assert (perr <= pos_tol).mean() >= frac, (perr <= pos_tol).mean()
     ok = same_obj.copy()
     ok[same_obj] = perr <= pos_tol
+    bez = np.isin(c["obj"], bezier_objs)
+    if (same_obj & bez).any():
+        pb = perr_all[same_obj & bez]
+        print(f"Bezier HitPoints: {pb.size}, within {pos_tol:g}: {(pb <= pos_tol).mean():.5f}, median {np.median(pb):.2e}, max {pb.max():.2e}")
+        assert (pb > pos_tol).sum() <= (1 - bezier_frac) * pb.size + slack, ((pb <= pos_tol).mean(), pb.size)
     # analytic objects: fp32 products of identical inputs; Bezier objects are textured with (u, t), and
     # t differs at the Newton scale (1e-5 .. 1e-3), i.e. a small fraction of a texel
-    bez = np.isin(c["obj"], bezier_objs)
     assert np.allclose(g["wgt"][ok & ~bez], c["wgt"][ok & ~bez], rtol=2e-5, atol=1e-6)
     assert np.allclose(g["wgt"][ok & bez], c["wgt"][ok & bez], rtol=0, atol=2e-3)
-    assert np.allclose(g["n"][ok], c["n"][ok], rtol=0, atol=5e-2)
+    # normals: analytic ones are the same fp64 value stored as fp32 (measured 3e-8); Bezier normals come from the
+    # derivatives at the solved (u, v): median 1e-6, and where the solve landed 1e-3 away the normal turns with it
+    assert np.allclose(g["n"][ok & ~bez], c["n"][ok & ~bez], rtol=0, atol=1e-7)
+    if (ok & bez).any():
+        nerr = np.abs(g["n"][ok & bez] - c["n"][ok & bez]).max(axis=1)
+        assert np.median(nerr) <= 1e-5 and (nerr > 1e-3).sum() <= 0.03 * nerr.size + slack and nerr.max() <= 0.1, (np.median(nerr), nerr.max())
     assert (g["R2"] == 2.0).all() and (g["N"] == 0).all()
     return ok.mean()
 
@@ -257,8 +275,11 @@ def test_eye_pass_hitpoints_teapot(gpu):
     o = _oracle(scene)
     o.eye_pass(cam, SEED)
     g, c = gpu.hitpoints(), o.hitpoints()
-    ok = _compare_hitpoints(g, c, 1e-3, 0.97, bezier_objs=(8,))
+    ok = _compare_hitpoints(g, c, 1e-3, 0.999, bezier_objs=(8,), slack=2)          # 75 teapot HitPoints: one of them 2e-3 off
     print("teapot hitpoints within 1e-3:", ok)
+    o32 = _oracle(scene, newton_fp32=True)
+    o32.eye_pass(cam, SEED)
+    _compare_hitpoints(g, o32.hitpoints(), 1e-3, 0.999, bezier_objs=(8,), slack=2)
     # the oracle solves every patch whose box the ray enters (Bezier.h:248-260); the GPU solves them nearest box
     # first and skips those that cannot hold a nearer hit, so it counts fewer solves for the same HitPoints
     assert 0.2 * o.counters()["newton_calls"] <= gpu.counters()["newton_calls"] <= o.counters()["newton_calls"]
@@ -269,7 +290,8 @@ def _image_parity(g, c, frac=0.995, linf=1e-3, mae=1e-4):
     assert mean > 0
     diff = np.abs(g - c).max(axis=2) / mean
     good = (diff <= linf).mean()
-    print(f"image parity: mean {mean:.5g}, within {linf:g}: {good:.5f}, MAE/mean {diff.mean():.3g}, max {diff.max():.3g}")
+    print(f"image parity: mean {mean:.5g}, within {linf:g}: {good:.5f}, outliers {int((diff > linf).sum())} of {diff.size}, "
+          f"MAE/mean {diff.mean():.3g}, max {diff.max():.3g}")
     assert good >= frac, good
     assert diff.mean() <= mae, diff.mean()
 
@@ -302,16 +324,16 @@ def test_photon_pass_image_teapot(gpu):
     gpu.set_scene(scene)
     gpu.eye_pass(cam, SEED)
     gpu.photon_pass(100, 100, SEED)
-    o = _oracle(scene)
-    o.eye_pass(cam, SEED)
-    o.photon_pass(100, 100, SEED)
-    cg, co = gpu.counters(), o.counters()
-    assert cg["photons"] == co["photons"]
-    assert cg["segments"] == pytest.approx(co["segments"], rel=5e-3)
-    assert cg["accepted"] == pytest.approx(co["accepted"], rel=2e-2)
-    # Bezier hits differ at the Newton residual scale, so teapot pixels and photons that touched the
-    # teapot are allowed to differ: 97 % of pixels within 1e-3 of the mean, MAE 2e-3
-    _image_parity(gpu.resolve(), o.resolve(), frac=0.97, mae=2e-3)
+    img = gpu.resolve()
+    for fp32 in (True, False):       # the oracle the tolerance is defined against, and the all-fp64 floor beside it
+        o = _oracle(scene, newton_fp32=fp32)
+        o.eye_pass(cam, SEED)
+        o.photon_pass(100, 100, SEED)
+        cg, co = gpu.counters(), o.counters()
+        assert cg["photons"] == co["photons"]
+        for k in ("segments", "deposits", "candidates", "accepted"):      # measured: equal
+            assert cg[k] == pytest.approx(co[k], rel=1e-3), k
+        _image_parity(img, o.resolve())                                  # measured: every pixel within 1e-3, MAE 4e-7
 
 
 def test_photon_sharding_and_batches(gpu):
@@ -368,7 +390,7 @@ def _random_room(rng, with_teapot):
 def test_random_rooms_whole_iteration(gpu, with_teapot):
     """Eye pass, photon pass and resolve over rooms drawn at random, against the oracle: the same HitPoints (pixel and
     node of the eye-path tree), the same tallies, the same image.  Analytic rooms to the analytic tolerances; with a
-    teapot to those of the Bezier tests (fp32 Newton on the GPU)."""
+    teapot to the stated image tolerance, against the oracle with Newton in fp32."""
     rng = np.random.default_rng(7 + int(with_teapot))
     cam = scenes.default_camera(96, 72)
     for trial in range(3 if with_teapot else 5):
@@ -377,7 +399,7 @@ def test_random_rooms_whole_iteration(gpu, with_teapot):
         gpu.set_scene(s)
         gpu.eye_pass(cam, SEED + trial)
         gpu.photon_pass(150, 100, SEED + trial)
-        o = _oracle(s)
+        o = _oracle(s, newton_fp32=with_teapot)
         o.eye_pass(cam, SEED + trial)
         o.photon_pass(150, 100, SEED + trial)
         g, c = gpu.hitpoints(), o.hitpoints()
@@ -393,11 +415,12 @@ def test_random_rooms_whole_iteration(gpu, with_teapot):
                 assert cg[k] == pytest.approx(co[k], rel=2e-3), (trial, k)
             assert (diff <= 1e-3).mean() >= 0.999 and diff.mean() <= 1e-5, (trial, (diff <= 1e-3).mean(), diff.mean())
         else:
+            # measured over these rooms: the same (pixel, node) set, tallies within 5e-5, >= 99.9 % of the pixels within 1e-3, MAE <= 5.3e-5
             common = np.intersect1d(_key(g), _key(c))
-            assert len(common) >= 0.99 * len(c) and abs(len(g) - len(c)) <= 0.01 * len(c), (trial, len(g), len(c), len(common))
+            assert len(common) >= 0.999 * len(c) and abs(len(g) - len(c)) <= 0.001 * len(c), (trial, len(g), len(c), len(common))
             for k in ("segments", "deposits", "candidates", "accepted", "eye_segments"):
-                assert cg[k] == pytest.approx(co[k], rel=3e-2), (trial, k)
-            assert (diff <= 2e-3).mean() >= 0.99 and diff.mean() <= 1e-3, (trial, (diff <= 2e-3).mean(), diff.mean())
+                assert cg[k] == pytest.approx(co[k], rel=1e-3), (trial, k)
+            assert (diff <= 1e-3).mean() >= 0.995 and diff.mean() <= 1e-4, (trial, (diff <= 1e-3).mean(), diff.mean())
         print(f"room {trial}: {len(c)} HitPoints, {co['deposits']} deposits, image within tolerance {(diff <= 1e-3).mean():.4f}, MAE/mean {diff.mean():.2e}")
 
 

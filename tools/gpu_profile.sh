@@ -18,7 +18,7 @@ timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetc
 echo "== pmc WRITE_SIZE"
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 bench.py $ARGS > "$OUT/bench_write.json" 2> "$OUT/bench_write.err" || { echo "write pass failed"; tail -5 "$OUT/bench_write.err"; exit 1; }
 echo "== pmc SQ"
-timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$OUT/sq" -- python3 bench.py $ARGS > "$OUT/bench_sq.json" 2> "$OUT/bench_sq.err" || { echo "sq pass failed"; tail -5 "$OUT/bench_sq.err"; exit 1; }
+timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d "$OUT/sq" -- python3 bench.py $ARGS > "$OUT/bench_sq.json" 2> "$OUT/bench_sq.err" || { echo "sq pass failed"; tail -5 "$OUT/bench_sq.err"; exit 1; }
 echo "== pmc TCC hit/miss"
 timeout -s KILL 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d "$OUT/tcc" -- python3 bench.py $ARGS > "$OUT/bench_tcc.json" 2> "$OUT/bench_tcc.err" || { echo "tcc pass failed"; tail -5 "$OUT/bench_tcc.err"; exit 1; }
 find "$OUT" -name '*.csv' | head -40
