@@ -48,6 +48,8 @@ struct DevObject {
     int flags;
     int tex_rows, tex_cols;     // the object's texture, copied here so that a lookup starts from LDS (texture < 0: unused)
     unsigned tex_off;           // first texel in the packed uchar4 array
+    int pad_;
+    double inv_radius;          // sphere: 1 / radius
 };
 
 struct TexDesc {
@@ -102,6 +104,10 @@ __device__ __forceinline__ uint32_t rng_base(uint64_t seed, uint32_t stream) {
 __device__ __forceinline__ uint32_t rng_sub(uint32_t base, uint32_t path, uint32_t vertex, uint32_t purpose) {
     return mm3(mm3(base, path), (vertex << 8) | purpose);
 }
+// the same in two steps, so that the draws of one path vertex share the hash of the path: rng_sub(base, path, v, p) ==
+// rng_vertex(rng_path(base, path), v, p)
+__device__ __forceinline__ uint32_t rng_path(uint32_t base, uint32_t path) { return mm3(base, path); }
+__device__ __forceinline__ uint32_t rng_vertex(uint32_t path_hash, uint32_t vertex, uint32_t purpose) { return mm3(path_hash, (vertex << 8) | purpose); }
 __device__ __forceinline__ uint32_t rng_bits(uint32_t sub, uint32_t idx) { return fmix3(mm3(sub, idx) ^ 24u) >> 8; }
 __device__ __forceinline__ double rng_u01(uint32_t sub, uint32_t idx) { return (double)rng_bits(sub, idx) * (1.0 / 16777216.0); }
 __device__ __forceinline__ float rng_u01f(uint32_t sub, uint32_t idx) { return (float)rng_bits(sub, idx) * (1.0f / 16777216.0f); }
@@ -146,9 +152,60 @@ __device__ __forceinline__ d3 get_unit(d3 v) {                                  
     double mo = sqrt(dot(v, v));
     return is_zero(mo) ? v : v * (1.0 / mo);
 }
+// 1 / sqrt(s) and sqrt(s) to the last place or two from the hardware's reciprocal square root (26 bits) and two Newton
+// steps: a third of the instructions of the correctly rounded sqrt followed by a division.  The reference's results (sqrt
+// and 1 / mo, each rounded) are themselves that far from the exact value, so this is rounding-level, like the FMA
+// contraction of the other expressions.
+#ifndef SPPM_FAST_UNIT
+#define SPPM_FAST_UNIT 1
+#endif
+__device__ __forceinline__ double rsqrt_nr(double s) {
+    double y = __builtin_amdgcn_rsq(s);
+    y = y * fma(-0.5 * s, y * y, 1.5);
+    y = y * fma(-0.5 * s, y * y, 1.5);
+    return y;
+}
+// 1 / x to the last place or two: the hardware's reciprocal and two Newton steps
+__device__ __forceinline__ double rcp_nr(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(y, fma(-x, y, 1.0), y);
+    y = fma(y, fma(-x, y, 1.0), y);
+    return y;
+}
+#ifndef SPPM_FAST_DIV
+#define SPPM_FAST_DIV 1
+#endif
+__device__ __forceinline__ double sqrt_nr(double s) {
+#if SPPM_FAST_UNIT
+    return s > 0.0 ? s * rsqrt_nr(s) : 0.0;
+#else
+    return sqrt(s);
+#endif
+}
+// Vec3::GetUnit (Vec3.h:56) for a vector of any length: |v| < 1e-4 (i.e. |v|^2 < 1e-8) is returned as it is, as there.
+__device__ __forceinline__ d3 get_unit_any(d3 v) {
+#if SPPM_FAST_UNIT
+    const double s = dot(v, v);
+    return (s < 1e-8) ? v : v * rsqrt_nr(s);
+#else
+    return get_unit(v);
+#endif
+}
+// Vec3::GetUnit for a vector that is of unit length but for rounding — the reflection, refraction or rotation of unit
+// vectors, a sphere's radius vector divided by the radius: v / |v| = v (1.5 - 0.5 |v|^2) up to (3/8)(|v|^2 - 1)^2, which
+// is below 4e-19 inside the guard; any other input takes the general path.
+__device__ __forceinline__ d3 get_unit_near1(d3 v) {
+#if SPPM_FAST_UNIT
+    const double s = dot(v, v);
+    if (fabs(s - 1.0) < 1e-9) return v * fma(-0.5, s, 1.5);
+    return get_unit_any(v);
+#else
+    return get_unit(v);
+#endif
+}
 __device__ __forceinline__ d3 get_refl(d3 v, d3 n) { return v - n * (2 * dot(v, n)); }     // Vec3.h:80-83
 __device__ __forceinline__ d3 get_anormal(d3 v) {                                          // Vec3.h:85-89
-    return (v.x == 0 && v.y == 0) ? mk(1, 0, 0) : get_unit(mk(v.y, -v.x, 0));
+    return (v.x == 0 && v.y == 0) ? mk(1, 0, 0) : get_unit_any(mk(v.y, -v.x, 0));
 }
 __device__ __forceinline__ d3 rotated(d3 v, d3 a, double angle) {                          // Vec3.h:99-115
     if (fabs(angle) < SPPM_EPS) return v;
@@ -171,18 +228,18 @@ __device__ __forceinline__ d3 rotated(d3 v, d3 a, double angle) {               
 // when |angle| < 1e-4: for theta that needs u1 > 1 - 1e-8, which a 24-bit uniform never reaches; for phi
 // the early return is kept (cos = 1, sin = 0).
 __device__ __forceinline__ d3 rand_refl(d3 n, double u1, double u2) {
-    const double cost = sqrt(u1), sint = sqrt(1.0 - u1);
+    const double cost = sqrt_nr(u1), sint = sqrt_nr(1.0 - u1);
     const double phi = 2 * SPPM_PI * u2;
     double sp = 0.0, cp = 1.0;
     if (!(fabs(phi) < SPPM_EPS)) sincos(phi, &sp, &cp);
     const d3 a = get_anormal(n);
     const d3 b = cross(a, n);
-    return get_unit(n * cost + (b * cp + a * sp) * sint);
+    return get_unit_near1(n * cost + (b * cp + a * sp) * sint);
 }
 __device__ __forceinline__ d3 refracted(d3 I, d3 N, double n) {                            // Vec3.h:124-134
     double cosI = -dot(N, I);
     double cosR2 = 1 - (1 - cosI * cosI) * (n * n);
-    return (cosR2 > SPPM_EPS) ? I * n + N * (n * cosI - sqrt(cosR2)) : get_refl(I, N);
+    return (cosR2 > SPPM_EPS) ? I * n + N * (n * cosI - sqrt_nr(cosR2)) : get_refl(I, N);
 }
 
 __device__ __forceinline__ TexDesc tex_of(const DevObject& ob) {
@@ -541,7 +598,9 @@ __device__ __forceinline__ void subbox_prune(const float* __restrict__ sub_box, 
 // solves the hit patches cooperatively, nearest box first, and stops as soon as no remaining box can hold
 // a hit nearer than the best one (aabb_entry_lb).  On return the ray's lane holds (t,u,v,patch) of the
 // nearest accepted patch or patch = -1.
-__device__ __forceinline__ void bezier_coop(const SceneView& S, const DevObject& ob, bool need, d3 o, d3 d, uint32_t sub, float bound,
+// path_hash / vertex: the ray's random stream (rng_path of its pixel or photon, its path vertex); the hash state of its
+// Newton draws is only formed for the one ray being solved, on the scalar unit.
+__device__ __forceinline__ void bezier_coop(const SceneView& S, const DevObject& ob, bool need, d3 o, d3 d, uint32_t path_hash, uint32_t vertex, float bound,
                                             float& out_t, float& out_u, float& out_v, int& out_patch, uint32_t& newton_calls) {
     const int lane = lane_id();
     out_patch = -1; out_t = (float)SPPM_MAX_NUM; out_u = 0; out_v = 0;
@@ -552,7 +611,7 @@ __device__ __forceinline__ void bezier_coop(const SceneView& S, const DevObject&
         m &= m - 1;
         d3 so = mk(bcast_d(o.x, src), bcast_d(o.y, src), bcast_d(o.z, src));
         d3 sd = mk(bcast_d(d.x, src), bcast_d(d.y, src), bcast_d(d.z, src));
-        uint32_t ssub = bcast_u(sub, src);
+        const uint32_t ssub = rng_vertex(bcast_u(path_hash, src), bcast_u(vertex, src), P_NEWTON);
         const float sbound = bcast_f(bound, src);
         float pt = (float)SPPM_MAX_NUM, pu = (float)SPPM_MAX_NUM, pv = (float)SPPM_MAX_NUM;  // para = MAX_VEC3
         int pidx = -1;
@@ -637,7 +696,11 @@ __device__ __forceinline__ void analytic_nearest(const SceneView& S, bool active
         if (type == OBJ_PLANE) {
             double project = dot(d, n);
             if (active && !is_zero(project)) {
+#if SPPM_FAST_DIV
+                double dist = dot(p0 - o, n) * rcp_nr(project);      // the quotient to the last place or two, in half the instructions
+#else
                 double dist = dot(p0 - o, n) / project;
+#endif
                 if (dist > SPPM_EPS && dist < best) { best = dist; bobj = a; binside = 0; }
             }
         } else if (type == OBJ_SPHERE) {
@@ -645,7 +708,7 @@ __device__ __forceinline__ void analytic_nearest(const SceneView& S, bool active
             double project = dot(L, d);
             double det2 = radius * radius - (dot(L, L) - project * project);
             if (active && !(det2 < SPPM_EPS)) {
-                double det = sqrt(det2);
+                double det = sqrt_nr(det2);
                 double dist1 = project - det, dist2 = project + det;
                 if (!(dist2 < SPPM_EPS)) {
                     const double dist = (dist1 > SPPM_EPS) ? dist1 : dist2;
@@ -658,7 +721,7 @@ __device__ __forceinline__ void analytic_nearest(const SceneView& S, bool active
 }
 
 // Bezier objects, solved inside the calling wave (Bezier.h:240-282).
-__device__ __forceinline__ void bezier_nearest_coop(const SceneView& S, bool active, d3 o, d3 d, uint32_t newton_sub, Near& nr, uint32_t& newton_calls) {
+__device__ __forceinline__ void bezier_nearest_coop(const SceneView& S, bool active, d3 o, d3 d, uint32_t path_hash, uint32_t vertex, Near& nr, uint32_t& newton_calls) {
 #ifdef ABLATE_BEZIER
     return;
 #endif
@@ -668,7 +731,7 @@ __device__ __forceinline__ void bezier_nearest_coop(const SceneView& S, bool act
         bool need = active && aabb_hit(ob.bmin, o, d);
         float t, u, v;
         int patch;
-        bezier_coop(S, ob, need, o, d, newton_sub, (float)nr.dist, t, u, v, patch, newton_calls);
+        bezier_coop(S, ob, need, o, d, path_hash, vertex, (float)nr.dist, t, u, v, patch, newton_calls);
         if (need && patch >= 0) near_consider(nr, (double)t, a, 0, patch, t, u, v);
     }
 }
@@ -755,7 +818,11 @@ __device__ __forceinline__ Hit finish_hit(const SceneView& S, d3 o, d3 d, const 
             }
         } else if (ob.type == OBJ_SPHERE) {
             d3 c = ld3(ob.p0);
+#if SPPM_FAST_UNIT
+            h.n = get_unit_near1((h.pos - c) * ob.inv_radius);       // |pos - c| is the radius but for the rounding of pos
+#else
             h.n = get_unit(h.pos - c);
+#endif
             if (ob.texture >= 0) {                                                        // Obj.h:140-153
                 const d3 texU = mk(0, 0.70710678118654757, -0.70710678118654757), texV = mk(1, 0, 0);
                 d3 N = h.n;
@@ -774,7 +841,7 @@ __device__ __forceinline__ Hit finish_hit(const SceneView& S, d3 o, d3 d, const 
             patch_eval(S.patch_cp + nr.patch * 48, nr.u, nr.v, Sp, Su, Sv);   // control points read straight from LDS
             d3 N = cross(mk(Su.x, Su.y, Su.z), mk(Sv.x, Sv.y, Sv.z));
             if (dot(N, d) > 0) N = neg(N);
-            h.n = get_unit(N);
+            h.n = get_unit_any(N);
             // GetColor(u, t): the second texture coordinate is the ray parameter (Bezier.h:278)
             if (ob.texture >= 0) tex_fetch(tex_of(ob), S.texels, (double)nr.u, (double)nr.t, h.tap);
         }
@@ -784,11 +851,11 @@ __device__ __forceinline__ Hit finish_hit(const SceneView& S, d3 o, d3 d, const 
 
 // Scene::NearCollide with the Bezier solves done inside the wave.  All lanes of the wave must
 // call this together; lanes with active = false take part but get obj = -1.
-__device__ __forceinline__ Hit near_collide(const SceneView& S, bool active, d3 o, d3 d, uint32_t newton_sub, uint32_t& newton_calls) {
+__device__ __forceinline__ Hit near_collide(const SceneView& S, bool active, d3 o, d3 d, uint32_t path_hash, uint32_t vertex, uint32_t& newton_calls) {
     Near nr;
     near_init(nr);
     analytic_nearest(S, active, o, d, nr);
-    bezier_nearest_coop(S, active, o, d, newton_sub, nr, newton_calls);
+    bezier_nearest_coop(S, active, o, d, path_hash, vertex, nr, newton_calls);
     return finish_hit(S, o, d, nr);
 }
 

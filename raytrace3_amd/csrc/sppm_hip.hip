@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
                             const double m = x * x + y * y + z * z;
                             if (!(m > 1 || m < SPPM_EPS)) break;
                         }
-                        const d3 u = get_unit(mk(x, y, z));
+                        const d3 u = get_unit_any(mk(x, y, z));
                         emit_dir[3 * e + 0] = u.x; emit_dir[3 * e + 1] = u.y; emit_dir[3 * e + 2] = u.z;
                     }
                 }
@@ -374,10 +374,11 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
                         const int row = (int)prow, col = (int)pcol;
                         o = ld3(tp.pos);
                         // Camera::emit(y = row, x = col), Camera.h:18-22
-                        d = get_unit(ld3(tp.du) * ((col + 0.5) / tp.w - 0.5) + ld3(tp.dv) * ((row + 0.5) / tp.h - 0.5) + ld3(tp.dir));
+                        d = get_unit_any(ld3(tp.du) * ((col + 0.5) / tp.w - 0.5) + ld3(tp.dv) * ((row + 0.5) / tp.h - 0.5) + ld3(tp.dir));
                         carry[0] = carry[1] = carry[2] = 1.0f;
                     } else {
-                        const DevLight& L = tp.lights[(g / tp.per_round) % (unsigned long long)tp.n_lights];
+                        // Raytracer.h:220-233: round by round, light by light; one light (the reference's scene) needs no division
+                        const DevLight& L = tp.lights[tp.n_lights == 1 ? 0u : (uint32_t)(((uint32_t)g / tp.per_round) % (uint32_t)tp.n_lights)];
                         const uint32_t e = (uint32_t)(my - chunk_base);                   // the direction drawn when the chunk was claimed
                         d = mk(emit_dir[3 * e + 0], emit_dir[3 * e + 1], emit_dir[3 * e + 2]);
                         o = ld3(L.pos);                                                   // Light::emit, Light.h:8-13
@@ -396,7 +397,8 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
 
         // ---- Scene::NearCollide for lanes that carry an untraced ray
         const bool tracing = active && !pending;
-        const uint32_t sub = rng_sub(tp.rng, id, (uint32_t)(MODE == MODE_EYE ? node : dep), P_NEWTON);
+        const uint32_t path_hash = rng_path(tp.rng, id);        // shared by the vertex's Newton, roulette and bounce draws
+        const uint32_t nvertex = (uint32_t)(MODE == MODE_EYE ? node : dep);
         bool park = false;
         uint64_t words[SPPM_MASK_WORDS] = {0, 0, 0, 0};
         if (__any(tracing)) {
@@ -405,7 +407,7 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
             analytic_nearest(S, tracing, o, d, a);
             STAMP(1);
             if (COOP) {
-                bezier_nearest_coop(S, tracing, o, d, sub, a, ncalls);
+                bezier_nearest_coop(S, tracing, o, d, path_hash, nvertex, a, ncalls);
                 STAMP(2);
             } else {
                 bezier_patch_masks(S, tracing, o, d, words);
@@ -447,7 +449,7 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
                     r.adist = nr.dist; r.aobj = nr.obj; r.ainside = nr.inside;
                     r.carry[0] = carry[0]; r.carry[1] = carry[1]; r.carry[2] = carry[2];
                     r.id = id; r.dep = dep; r.node = node;
-                    r.task_first = (uint32_t)tb; r.task_count = tasks_fit ? my_tasks : 0u; r.sub = sub; r.pad = 0;
+                    r.task_first = (uint32_t)tb; r.task_count = tasks_fit ? my_tasks : 0u; r.sub = rng_vertex(path_hash, nvertex, P_NEWTON); r.pad = 0;
                     tp.park_out[slot] = r;
                     uint32_t k = 0;
 #pragma unroll
@@ -486,10 +488,10 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
                 const DevObject& ob = S.objs[hit.obj];
                 const bool has_refl = ob.flags & F_REFL, has_refr = ob.flags & F_REFR;
                 d3 refl_d = mk(0, 0, 0), refr_d = mk(0, 0, 0);
-                if (has_refl) refl_d = get_unit(get_refl(d, hit.n));                      // Raytracer.h:320-326
+                if (has_refl) refl_d = get_unit_near1(get_refl(d, hit.n));                // Raytracer.h:320-326
                 if (has_refr) {                                                           // Raytracer.h:327-336
                     const double refrn = hit.inside ? ob.refrn : 1 / ob.refrn;
-                    refr_d = get_unit(refracted(d, hit.inside ? neg(hit.n) : hit.n, refrn));
+                    refr_d = get_unit_near1(refracted(d, hit.inside ? neg(hit.n) : hit.n, refrn));
                 }
                 float hc[3];
                 hit_color(hit, hc);                                                       // the texels were asked for in finish_hit
@@ -556,20 +558,20 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
                     keep = !tp.occ || tp.occ[bk] != 0;
                 }
                 // Obj::Roulette, Obj.h:30-45
-                const double r = rng_u01(rng_sub(tp.rng, id, vertex, P_ROULETTE), 0) * ob.allr;
+                const double r = rng_u01(rng_vertex(path_hash, vertex, P_ROULETTE), 0) * ob.allr;
                 d3 nd;
                 if (ob.diffr > r) {                                                       // DIFF, Raytracer.h:163-166
-                    const uint32_t ds = rng_sub(tp.rng, id, vertex, P_DIFFUSE);
+                    const uint32_t ds = rng_vertex(path_hash, vertex, P_DIFFUSE);
 #ifdef ABLATE_BOUNCE
                     nd = get_unit(hit.n + mk(rng_u01(ds, 0) - 0.5, rng_u01(ds, 1) - 0.5, 0.1));
 #else
                     nd = rand_refl(hit.n, rng_u01(ds, 0), rng_u01(ds, 1));
 #endif
                 } else if (ob.diffr + ob.reflr > r) {                                     // REFL, Raytracer.h:177-181
-                    nd = get_unit(get_refl(d, hit.n));
+                    nd = get_unit_near1(get_refl(d, hit.n));
                 } else {                                                                  // REFR, Raytracer.h:182-190
                     const double refrn = hit.inside ? ob.refrn : 1 / ob.refrn;
-                    nd = get_unit(refracted(d, hit.inside ? neg(hit.n) : hit.n, refrn));
+                    nd = get_unit_near1(refracted(d, hit.inside ? neg(hit.n) : hit.n, refrn));
                 }
                 float hc[3];
                 hit_color(hit, hc);                                                       // the texels were asked for in finish_hit
@@ -842,6 +844,9 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_reduce_close(const uint32
 #ifndef GATHER_ROWS
 #define GATHER_ROWS 3        // 78 VGPRs: three gather workgroups and one trace workgroup fit a CU's register files together
 #endif
+#ifndef GATHER_DEFER_WGT
+#define GATHER_DEFER_WGT 1   // sum the deposits' flux and multiply by the HitPoint's weight once (Raytracer.h:156 summed over the photons)
+#endif
 #ifndef GATHER_TILE
 #define GATHER_TILE 16u      // HitPoints per tile (<= 16: one accumulator lane per HitPoint in every DPP row)
 #endif
@@ -974,7 +979,9 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
                 const double hx = bcast_d(mp.x, j), hy = bcast_d(mp.y, j), hz = bcast_d(mp.z, j);
                 const float nx = bcast_f(mnr.x, j), ny = bcast_f(mnr.y, j), nz = bcast_f(mnr.z, j);
                 const double R2 = FIXED_R2 ? SPPM_INIT_R2 : bcast_d(mr2, j);
+#if !GATHER_DEFER_WGT
                 const float wr = bcast_f(mw.x, j), wg = bcast_f(mw.y, j), wb = bcast_f(mw.z, j);
+#endif
                 float pr = 0, pg = 0, pb = 0;
                 uint32_t pn = 0;
                 row_tests += (uint32_t)rows;
@@ -992,10 +999,14 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
                         cand += (uint32_t)__popcll(cm);
                         pn += FIXED_R2 ? (uint32_t)__popcll(cm & __builtin_amdgcn_ballot_w64(facing))
                                        : (uint32_t)__popcll(cm & __builtin_amdgcn_ballot_w64(facing) & __builtin_amdgcn_ballot_w64(inr));
-                        if (ok) {   // three FMAs under the lane mask (no per-channel select)
+                        if (ok) {   // three operations under the lane mask (no per-channel select)
+#if GATHER_DEFER_WGT
+                            pr += bfr[r]; pg += bfg[r]; pb += bfb[r];
+#else
                             pr = fmaf(wr, bfr[r], pr);
                             pg = fmaf(wg, bfg[r], pg);
                             pb = fmaf(wb, bfb[r], pb);
+#endif
                         }
                     }
                 }
@@ -1029,6 +1040,9 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
     tr += __shfl_xor(tr, 16, 64); tg += __shfl_xor(tg, 16, 64); tb += __shfl_xor(tb, 16, 64);
     tr += __shfl_xor(tr, 32, 64); tg += __shfl_xor(tg, 32, 64); tb += __shfl_xor(tb, 32, 64);
     if (valid && tn) {
+#if GATHER_DEFER_WGT
+        tr *= mw.x; tg *= mw.y; tb *= mw.z;        // the HitPoint's weight, the same for every deposit, multiplies the flux sums once
+#endif
         if (PIECE) {
             float* t = (float*)&hp_tao[mine];
             atomicAdd(t + 0, tr); atomicAdd(t + 1, tg); atomicAdd(t + 2, tb);
@@ -1230,7 +1244,7 @@ __global__ void __launch_bounds__(256) k_debug_near_collide(SceneParams sp, uint
     const bool active = i < n;
     d3 o = active ? ld3(org + 3 * (size_t)i) : mk(0, 0, 0), d = active ? ld3(dir + 3 * (size_t)i) : mk(0, 0, 1);
     uint32_t ncalls = 0;
-    Hit h = near_collide(S, active, o, d, rng_sub(rng, i, 0u, P_NEWTON), ncalls);
+    Hit h = near_collide(S, active, o, d, rng_path(rng, i), 0u, ncalls);
     if (active) {
         sppm_collision c;
         c.pos[0] = h.pos.x; c.pos[1] = h.pos.y; c.pos[2] = h.pos.z;
@@ -1660,6 +1674,8 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
             o.bmin[k] = 1e20; o.bmax[k] = -1e20;
         }
         o.radius = so.radius; o.refrn = so.material.refrn;
+        o.inv_radius = so.radius != 0 ? 1.0 / so.radius : 0.0;
+        o.pad_ = 0;
         o.diffr = (so.material.diff[0] + so.material.diff[1] + so.material.diff[2]) / 3;  // Obj.h:11-16, Vec3.h:116-119
         o.reflr = (so.material.refl[0] + so.material.refl[1] + so.material.refl[2]) / 3;
         o.refrr = (so.material.refr[0] + so.material.refr[1] + so.material.refr[2]) / 3;
