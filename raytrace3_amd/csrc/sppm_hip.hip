@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
                 d3 refl_d = mk(0, 0, 0), refr_d = mk(0, 0, 0);
                 if (has_refl) refl_d = get_unit_near1(get_refl(d, hit.n));                // Raytracer.h:320-326
                 if (has_refr) {                                                           // Raytracer.h:327-336
-                    const double refrn = hit.inside ? ob.refrn : 1 / ob.refrn;
+                    const double refrn = hit.inside ? ob.refrn : ob.inv_refrn;
                     refr_d = get_unit_near1(refracted(d, hit.inside ? neg(hit.n) : hit.n, refrn));
                 }
                 float hc[3];
@@ -558,19 +558,23 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
                     keep = !tp.occ || tp.occ[bk] != 0;
                 }
                 // Obj::Roulette, Obj.h:30-45
-                const double r = rng_u01(rng_vertex(path_hash, vertex, P_ROULETTE), 0) * ob.allr;
+                // A material with one lobe (every one of the reference's scene) has one outcome whatever r is: the draw, which
+                // no other draw depends on (counter-based streams), is then not even computed.
+                const int lobe = ob.lobe;
+                double r = 0;
+                if (__any(lobe == 0)) r = rng_u01(rng_vertex(path_hash, vertex, P_ROULETTE), 0) * ob.allr;
                 d3 nd;
-                if (ob.diffr > r) {                                                       // DIFF, Raytracer.h:163-166
+                if (lobe == F_DIFF || (lobe == 0 && ob.diffr > r)) {                      // DIFF, Raytracer.h:163-166
                     const uint32_t ds = rng_vertex(path_hash, vertex, P_DIFFUSE);
 #ifdef ABLATE_BOUNCE
                     nd = get_unit(hit.n + mk(rng_u01(ds, 0) - 0.5, rng_u01(ds, 1) - 0.5, 0.1));
 #else
                     nd = rand_refl(hit.n, rng_u01(ds, 0), rng_u01(ds, 1));
 #endif
-                } else if (ob.diffr + ob.reflr > r) {                                     // REFL, Raytracer.h:177-181
+                } else if (lobe == F_REFL || (lobe == 0 && ob.diffr + ob.reflr > r)) {    // REFL, Raytracer.h:177-181
                     nd = get_unit_near1(get_refl(d, hit.n));
                 } else {                                                                  // REFR, Raytracer.h:182-190
-                    const double refrn = hit.inside ? ob.refrn : 1 / ob.refrn;
+                    const double refrn = hit.inside ? ob.refrn : ob.inv_refrn;
                     nd = get_unit_near1(refracted(d, hit.inside ? neg(hit.n) : hit.n, refrn));
                 }
                 float hc[3];
@@ -1675,11 +1679,16 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
         }
         o.radius = so.radius; o.refrn = so.material.refrn;
         o.inv_radius = so.radius != 0 ? 1.0 / so.radius : 0.0;
-        o.pad_ = 0;
+        o.inv_refrn = so.material.refrn != 0 ? 1.0 / so.material.refrn : 0.0;
         o.diffr = (so.material.diff[0] + so.material.diff[1] + so.material.diff[2]) / 3;  // Obj.h:11-16, Vec3.h:116-119
         o.reflr = (so.material.refl[0] + so.material.refl[1] + so.material.refl[2]) / 3;
         o.refrr = (so.material.refr[0] + so.material.refr[1] + so.material.refr[2]) / 3;
         o.allr = o.diffr + o.reflr + o.refrr;
+        {   // Obj::Roulette (Obj.h:30-45) draws r in [0, allr): with one positive power the outcome does not depend on r
+            const int lobes = (o.diffr > 0) + (o.reflr > 0) + (o.refrr > 0);
+            o.lobe = 0;
+            if (lobes == 1) o.lobe = o.diffr > 0 ? F_DIFF : (o.reflr > 0 ? F_REFL : F_REFR);
+        }
         // Material::IsDiff etc.: !IsZero(vec), where IsZero(vec) is true if ANY component is ~0 (Element.h:16-18, Vec3.h:72-79)
         o.flags = (any_zero3(so.material.diff) ? 0 : F_DIFF) | (any_zero3(so.material.refl) ? 0 : F_REFL) |
                   (any_zero3(so.material.refr) ? 0 : F_REFR);
