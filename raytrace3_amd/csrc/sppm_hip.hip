@@ -1175,11 +1175,12 @@ __global__ void __launch_bounds__(256) k_gather_split(const PosKey* __restrict__
 // never exceeds; a bucket without a hit still gets a few slots (far down the open tunnel every batch hits other
 // cells, one photon each).  slack_sigma = 0 leaves no margin at all (tests use it to send deposits down the
 // overflow path).
-__global__ void k_bucket_room(const uint32_t* __restrict__ count, uint32_t n, float slack_sigma, uint32_t slack_add, uint32_t* __restrict__ room) {
+__global__ void k_bucket_room(const uint32_t* __restrict__ count, uint32_t n, float slack_sigma, uint32_t slack_add, uint32_t slack_empty,
+                              uint32_t* __restrict__ room) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t c = count[i];
-    room[i] = c ? c + (uint32_t)ceilf(slack_sigma * sqrtf((float)c)) + slack_add : (slack_add ? 8u : 0u);
+    room[i] = c ? c + (uint32_t)ceilf(slack_sigma * sqrtf((float)c)) + slack_add : slack_empty;
 }
 
 // ------------------------------------------------------------------ resolve (Raytracer.h:281-293)
@@ -1367,6 +1368,10 @@ struct sppm_ctx {
     sppm_camera cam{};
     DevBuf<RawHit> raw;
     DevBuf<ParkRec> park[2]; DevBuf<NewtonTask> ntask[2]; DevBuf<float4> nres;
+    uint64_t park_scale = 1;          // the eye pass's branch queue has been doubled this many times over (run_trace)
+    uint64_t branch_queue_min = 1u << 16;   // its smallest size (SPPM_BRANCH_QUEUE_MIN: tests shrink it to see it grow)
+    double dep_per_photon = 4.0;      // deposit slots per photon of a batch (measured 3.7 diffuse hits per photon, 1.9 stored, in the reference's
+                                      // open tunnel; at most 14): grows when a counting-sorted batch overflows them (sppm_photon_pass)
     uint64_t coop_threshold = 4096;   // rounds with fewer parked rays finish inside the trace kernel
     bool force_coop = false;
     bool photon_coop = true;
@@ -1405,7 +1410,12 @@ struct sppm_ctx {
     DevBuf<GatherPiece> pieces;  // queued row ranges of heavy cells (k_gather -> k_gather_split)
     // Direct placement of deposits (see TraceParams::place): the layout made from the histogram of an earlier batch
     bool place_enabled = true;            // SPPM_PLACE=0: every batch is counting-sorted
-    float place_sigma = 6.0f; uint32_t place_add = 16;   // room of a bucket = count + sigma * sqrt(count) + add
+    // room of a bucket = count + sigma * sqrt(count) + add, and `empty` slots for a bucket without a hit in the batch the
+    // layout was made from.  Measured at the bench scene (1 M photons, 2^20 buckets; room in deposits / deposits per pass
+    // that find their bucket full and take the slower overflow path): 6, 16, 8: 24.1 M / 40; 6, 4, 4: 15.2 M / 900;
+    // 5, 4, 4: 14.1 M / 1 000 (no measurable cost); 4, 8, 2 or 6, 4, 2: 14.2 M / 5 200 (gather + 4 %); 4, 4, 1: 11.4 M / 14 000 (+ 9 %).
+    float place_sigma = 5.0f; uint32_t place_add = 4;
+    uint32_t place_empty = 4;
     bool place_valid = false;
     uint32_t place_M = 0; uint64_t place_photons = 0, place_total = 0;
     DevBuf<uint32_t> place_room, place_start;
@@ -1535,6 +1545,10 @@ int sppm_create(sppm_ctx** out, int device_id) {
     if (const char* b = getenv("SPPM_DEP_FILTER")) ctx->dep_filter = atoi(b) != 0;
     if (const char* b = getenv("SPPM_PLACE")) ctx->place_enabled = atoi(b) != 0;
     if (const char* b = getenv("SPPM_PLACE_SIGMA")) { ctx->place_sigma = std::max(0.0f, (float)atof(b)); if (ctx->place_sigma == 0.0f) ctx->place_add = 0; }
+    if (const char* b = getenv("SPPM_PLACE_ADD")) ctx->place_add = (uint32_t)std::max(0, atoi(b));
+    if (const char* b = getenv("SPPM_PLACE_EMPTY")) ctx->place_empty = (uint32_t)std::max(0, atoi(b));
+    if (const char* b = getenv("SPPM_BRANCH_QUEUE_MIN")) ctx->branch_queue_min = (uint64_t)std::max(1, atoi(b));
+    if (const char* b = getenv("SPPM_DEP_PER_PHOTON")) ctx->dep_per_photon = std::min(14.0, std::max(0.01, atof(b)));
     if (const char* b = getenv("SPPM_VERBOSE")) ctx->verbose = atoi(b) != 0;
     if (const char* b = getenv("SPPM_SUBBOX")) ctx->use_sub_box = atoi(b) != 0;
     if (ctx->ctl.reserve(ctx->ctl_words()) != hipSuccess || ctx->counters.reserve(1) != hipSuccess) {
@@ -1819,7 +1833,10 @@ static uint64_t coprime_near(uint64_t n, uint64_t want) {
 
 static int trace_max_blocks(const sppm_ctx* ctx) { return ctx->num_cu * 4; }
 // output slots that can be left unused in open chunks (one chunk per wave slot of the largest trace grid)
-static uint64_t dep_slack(const sppm_ctx* ctx) { return (uint64_t)trace_max_blocks(ctx) * 4u * TRACE_SLOT_CHUNK; }
+// items: work items of the largest launch (a grid never has more workgroups than items / 256)
+static uint64_t dep_slack(const sppm_ctx* ctx, uint64_t items = ~0ull) {
+    return std::min<uint64_t>((uint64_t)trace_max_blocks(ctx), (items + 255) / 256 + 1) * 4u * TRACE_SLOT_CHUNK;
+}
 
 static int reset_ctl(sppm_ctx* ctx) {
     HIPCHK(hipMemsetAsync(ctx->ctl.p, 0, ctx->ctl_words() * sizeof(unsigned long long), ctx->stream));
@@ -1877,9 +1894,22 @@ static int read_queues(sppm_ctx* ctx, QueueState& q) {
     return SPPM_OK;
 }
 #define SPPM_RETRY_HITS (SPPM_E_CAPACITY + 100)
-static int overflow_code(sppm_ctx* ctx, const DevCounters& dc) {
+#define SPPM_RETRY_PARK (SPPM_E_CAPACITY + 101)
+#define SPPM_RETRY_DEP (SPPM_E_CAPACITY + 102)
+// Overflow bits: 1 HitPoint buffer, 2 ray / task queue, 4 deposit buffer or overflow list, 8 gather piece queue.  A pass whose
+// host is still there to run it again (the eye pass; a counting-sorted photon batch) retries with more room, told which by
+// the RETRY codes; everything else is an error.
+static int overflow_code(sppm_ctx* ctx, const DevCounters& dc, bool can_retry_queues = false) {
     if (dc.overflow == 0) return SPPM_OK;
     (void)hipMemsetAsync(&ctx->counters.p->overflow, 0, sizeof(unsigned int), ctx->stream);   // seen: clear
+    if (can_retry_queues && (dc.overflow & ~7u) == 0) {
+        if (dc.overflow & 4u) return SPPM_RETRY_DEP;
+        if (dc.overflow & 2u) return SPPM_RETRY_PARK;
+    }
+    if (dc.overflow & 4u) {   // a queued pass ran out of deposit slots: its result is lost, the next pass gets the worst-case room
+        ctx->dep_per_photon = SPPM_MAX_DEP + 1;
+        ctx->place_valid = false;
+    }
     if (dc.overflow & 14u) return fail(ctx, SPPM_E_CAPACITY, "a ray / task / deposit / gather-piece queue overflowed");
     return SPPM_RETRY_HITS;   // HitPoint buffer too small: the eye pass retries with more room
 }
@@ -1896,8 +1926,22 @@ static int overflow_code(sppm_ctx* ctx, const DevCounters& dc) {
 static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_first, uint64_t fresh_count, bool has_dual_lobe,
                      bool need_final_state, QueueState& q, bool* synced) {
     *synced = false;
-    const uint64_t park_cap = std::max<uint64_t>(fresh_count, 1u << 16);
-    const uint64_t task_cap = 16 * park_cap;
+    // Photons meet a Bezier object at random, a few lanes per wave, and so do eye rays once the pixels are
+    // dealt to the waves in a scattered order (TraceParams::pix_mul): solving in place costs less than the
+    // extra launches of a park round.  With pixels in row order the rays that meet the object are whole
+    // waves, which would serialise 64 solves each while the other waves idle: then they are parked and
+    // solved by k_newton (SPPM_EYE_SCATTER=0, or SPPM_PHOTON_COOP=0 for photons).
+    const bool first_coop = ctx->force_coop || ctx->coop_only || (mode == MODE_PHOTON && ctx->photon_coop) || (mode == MODE_EYE && ctx->eye_scatter);
+    // The ray and task queues are sized by what can reach them.  With in-wave solves nothing is parked for a solve: only
+    // the refraction branches of eye paths through a material that both reflects and refracts are queued (as fresh rays),
+    // at most one per path vertex, and their queue grows by doubling when a pass overflows it (park_scale; the eye pass
+    // retries like it does for the HitPoint buffer).  Parked solves (the non-default modes) can queue every work item
+    // with up to 16 patch tasks each.
+    const bool branches = mode == MODE_EYE && has_dual_lobe;
+    const uint64_t park_cap = !first_coop ? std::max<uint64_t>(fresh_count, 1u << 16)
+                              : branches  ? std::max<uint64_t>(fresh_count / 4, ctx->branch_queue_min) * ctx->park_scale
+                                          : (1u << 12);
+    const uint64_t task_cap = first_coop ? 16 : 16 * park_cap;
     if (task_cap > 0xffffffffull) return fail(ctx, SPPM_E_CAPACITY, "too many work items for one round");
     HIPCHK(ctx->park[0].reserve(park_cap)); HIPCHK(ctx->park[1].reserve(park_cap));
     HIPCHK(ctx->ntask[0].reserve(task_cap)); HIPCHK(ctx->ntask[1].reserve(task_cap));
@@ -1939,12 +1983,6 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
         return SPPM_OK;
     };
     tp.park_cap = park_cap; tp.task_cap = task_cap;
-    // Photons meet a Bezier object at random, a few lanes per wave, and so do eye rays once the pixels are
-    // dealt to the waves in a scattered order (TraceParams::pix_mul): solving in place costs less than the
-    // extra launches of a park round.  With pixels in row order the rays that meet the object are whole
-    // waves, which would serialise 64 solves each while the other waves idle: then they are parked and
-    // solved by k_newton (SPPM_EYE_SCATTER=0, or SPPM_PHOTON_COOP=0 for photons).
-    const bool first_coop = ctx->force_coop || ctx->coop_only || (mode == MODE_PHOTON && ctx->photon_coop) || (mode == MODE_EYE && ctx->eye_scatter);
     const bool legacy = (mode == MODE_PHOTON && !first_coop);   // photons with parked solves: every round looks at the counters
     if (int rc = set_round(0, true)) return rc;
     int first_blocks = blocks_for(fresh_count, first_coop);
@@ -1964,7 +2002,7 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
     for (int round = 0; round < 256; round++) {
         if (int rc = read_queues(ctx, q)) return rc;
         *synced = true;
-        if (int rc = overflow_code(ctx, q.dc)) return rc;
+        if (int rc = overflow_code(ctx, q.dc, first_coop)) return rc;
         const unsigned long long n_park = q.sc[cur ? SC_PARK1 : SC_PARK0], n_tasks = q.sc[cur ? SC_TASK1 : SC_TASK0];
         if (ctx->verbose) fprintf(stderr, "[sppm] mode %d round %d: %llu rays queued, %llu newton tasks\n", mode, round, n_park, n_tasks);
         if (n_park == 0) return SPPM_OK;
@@ -1990,7 +2028,7 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
     ctx->cam = *cam;
     ctx->have_eye = false;
     const uint64_t npx = (uint64_t)cam->w * cam->h;
-    uint64_t hit_cap = std::max<uint64_t>(2 * npx, 1 << 16) + dep_slack(ctx);
+    uint64_t hit_cap = std::max<uint64_t>(2 * npx, 1 << 16) + dep_slack(ctx, npx);
     if (!ctx->accumulate_stats) drop_spans(ctx);
     // ---- the hashed grid the HitPoints will be sorted into.  The eye kernel histograms them as it writes them, so the
     // bucket count is chosen BEFORE the trace, from the HitPoint count of the last eye pass at this resolution (a
@@ -2034,9 +2072,9 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
         int rc = run_trace(ctx, MODE_EYE, tp, 0, npx, ctx->has_dual_lobe, true, q, &synced);
         toc(ctx);
         if (rc == SPPM_OK) break;
-        if (rc != SPPM_RETRY_HITS) return rc;
-        if (attempt == 5) return fail(ctx, SPPM_E_CAPACITY, "HitPoint buffer overflowed after 5 capacity doublings");
-        hit_cap *= 2;
+        if (rc != SPPM_RETRY_HITS && rc != SPPM_RETRY_PARK) return rc;
+        if (attempt == 7) return fail(ctx, SPPM_E_CAPACITY, "HitPoint buffer or branch queue overflowed after 7 capacity doublings");
+        if (rc == SPPM_RETRY_HITS) hit_cap *= 2; else ctx->park_scale *= 2;
         if (!ctx->accumulate_stats) drop_spans(ctx);
     }
     // q is the state after the last launch: claimed slots of the raw array (with holes) and the HitPoints in them
@@ -2142,7 +2180,11 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
         batch = (uint64_t)ctx->rounds_per_update * ctx->n_lights * per_round;
         if (batch > (1ull << 24)) return fail(ctx, SPPM_E_INVALID, "more than 2^24 photons between two radius updates");
     }
-    const uint64_t dep_cap = batch * (SPPM_MAX_DEP + 1) + dep_slack(ctx);
+    // Deposit slots: dep_per_photon per photon of a batch, not the 14 a path could leave in a closed all-diffuse room (the
+    // reference's open tunnel leaves 3.7 diffuse hits per photon, of which 1.9 are stored).  A counting-sorted batch that
+    // overflows them is traced again with more (below); a placed batch only uses this buffer as its overflow list.
+    auto cap_for = [&](double per_photon) { return (uint64_t)std::ceil((double)batch * std::min<double>(per_photon, SPPM_MAX_DEP + 1)) + dep_slack(ctx, batch); };
+    uint64_t dep_cap = cap_for(ctx->dep_per_photon);
     HIPCHK(ctx->dep.reserve(dep_cap)); HIPCHK(ctx->sdep.reserve(std::max<uint64_t>(dep_cap, ctx->place_valid ? ctx->place_total : 0)));
     HIPCHK(ctx->place_over_max.reserve(1));
     TraceParams tp{};
@@ -2170,11 +2212,40 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
             tp.place = nullptr;
             lay_out = ctx->place_enabled && ctx->dep_filter && !sweeps && ctx->n_hp > 0 && count == batch;
             tp.dcount_all = lay_out ? ctx->dcount_all() : nullptr;
-            if (int rc = launch_pass_reset(ctx, false, ctx->cursor(), (lay_out ? 3 : 2) * ((size_t)M + 1))) return rc;   // + cursor, dcount (and dcount_all)
-            tic(ctx, PH_TRACE);
-            bool synced = false;
-            if (int rc = run_trace(ctx, MODE_PHOTON, tp, first, count, false, false, q, &synced)) return rc;
-            toc(ctx);
+            DevCounters first_failed{};
+            for (int attempt = 0;; attempt++) {
+                if (int rc = launch_pass_reset(ctx, false, ctx->cursor(), (lay_out ? 3 : 2) * ((size_t)M + 1))) return rc;   // + cursor, dcount (and dcount_all)
+                tic(ctx, PH_TRACE);
+                bool synced = false;
+                if (int rc = run_trace(ctx, MODE_PHOTON, tp, first, count, false, false, q, &synced)) return rc;
+                toc(ctx);
+                // A counting-sorted batch is where the deposit buffer can overflow with the host still at hand to trace it
+                // again: one look at the flags before the deposits are sorted and gathered (placed batches, the steady
+                // state, have no such wait).
+                if (int rc = read_queues(ctx, q)) return rc;
+                const int oc = overflow_code(ctx, q.dc, true);
+                if (oc == SPPM_OK) {
+                    if (attempt > 0) {
+                        // the photons of the failed attempts were tallied as well: back to the tallies after the first of them
+                        // (the stream is idle: read_queues waited for it)
+                        DevCounters fix = q.dc;
+                        fix.photons = first_failed.photons; fix.segments = first_failed.segments; fix.deposits = first_failed.deposits;
+                        fix.stored = first_failed.stored; fix.newton_calls = first_failed.newton_calls;
+                        HIPCHK(hipMemcpy(ctx->counters.p, &fix, offsetof(DevCounters, overflow), hipMemcpyHostToDevice));
+                    }
+                    break;
+                }
+                if (oc != SPPM_RETRY_DEP || attempt == 3) return oc < 0 ? oc : fail(ctx, SPPM_E_CAPACITY, "a ray / deposit queue overflowed");
+                if (attempt == 0) first_failed = q.dc;
+                // the slot counter ran on past the capacity: it says what the batch needs
+                const double need = (double)q.sc[SC_DEP] / (double)count;
+                ctx->dep_per_photon = std::min<double>(SPPM_MAX_DEP + 1, std::max(2.0 * ctx->dep_per_photon, need * 1.25));
+                dep_cap = cap_for(ctx->dep_per_photon);
+                if (ctx->verbose) fprintf(stderr, "[sppm] deposit buffer overflowed (%.2f slots per photon needed): retrying with %.2f\n", need, ctx->dep_per_photon);
+                HIPCHK(ctx->dep.reserve(dep_cap)); HIPCHK(ctx->sdep.reserve(std::max<uint64_t>(dep_cap, ctx->place_valid ? ctx->place_total : 0)));
+                fill_photon_params(ctx, tp, per_round, dep_cap, seed, replica, ctx->counters.p);
+                tp.dcount_all = lay_out ? ctx->dcount_all() : nullptr;
+            }
             tic(ctx, PH_SORT);
             if (int rc = launch_scan(ctx, ctx->dcount(), ctx->dstart.p, M, ctx->dep.p, nullptr, dep_cap)) return rc;   // + chunk tails -> holes
             hipLaunchKernelGGL(k_dep_scatter, dim3(ctx->num_cu * ctx->scatter_blocks_per_cu), dim3(256), 0, ctx->stream, ctx->dep.p, ctx->scalars() + SC_DEP,
@@ -2216,7 +2287,7 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
         if (lay_out) {
             HIPCHK(ctx->place_room.reserve((size_t)M + 1)); HIPCHK(ctx->place_start.reserve((size_t)M + 1));
             hipLaunchKernelGGL(k_bucket_room, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, ctx->dcount_all(), M, ctx->place_sigma,
-                               ctx->place_add, ctx->place_room.p);
+                               ctx->place_add, ctx->place_add ? ctx->place_empty : 0u, ctx->place_room.p);
             HIPCHK(hipGetLastError());
             if (int rc = launch_scan(ctx, ctx->place_room.p, ctx->place_start.p, M)) return rc;
             uint32_t total_room = 0;

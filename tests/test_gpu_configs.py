@@ -308,6 +308,40 @@ def test_batch_size_is_immaterial(gpu):
     small.close()
 
 
+def test_queues_sized_for_the_usual_case_grow_when_a_pass_needs_more(gpu, monkeypatch):
+    """Deposit slots are provided per photon for what the reference's scene needs (4, against the 14 a path could leave), the
+    eye pass's branch queue for a quarter of the pixels: a counting-sorted photon batch that overflows its deposit buffer
+    and an eye pass that overflows its branch queue are run again with more room, and give the pass a context with
+    ample room gives — HitPoints, per-HitPoint photon counts and every tally (the failed attempts are not counted twice)."""
+    scene, cam = _materials_scene(), scenes.default_camera(96, 72)        # two-lobe glass: the eye paths branch
+    gpu.set_scene(scene)
+    want = []
+    for replica in range(2):
+        gpu.eye_pass(cam, SEED, replica)
+        gpu.photon_pass(4000, 100, SEED, replica)
+        hp = gpu.hitpoints()
+        want.append((hp[np.argsort(_key(hp))], gpu.counters(), gpu.resolve()))
+    monkeypatch.setenv("SPPM_DEP_PER_PHOTON", "0.05")        # 20 000 slots (+ the waves' open chunks) for over a million deposits
+    monkeypatch.setenv("SPPM_BRANCH_QUEUE_MIN", "32")
+    monkeypatch.setenv("SPPM_PLACE", "0")                     # every batch counting-sorted
+    tight = SppmContext(0)
+    try:
+        tight.set_scene(scene)
+        for replica in range(2):
+            tight.eye_pass(cam, SEED, replica)
+            tight.photon_pass(4000, 100, SEED, replica)
+            hp = tight.hitpoints()
+            hp = hp[np.argsort(_key(hp))]
+            w_hp, w_c, w_img = want[replica]
+            assert np.array_equal(_key(hp), _key(w_hp)) and np.array_equal(hp["newN"], w_hp["newN"])
+            assert np.array_equal(hp["pos"], w_hp["pos"])
+            assert tight.counters() == w_c, (tight.counters(), w_c)
+            assert np.allclose(tight.resolve(), w_img, rtol=2e-4, atol=1e-6 * w_img.mean())
+        assert tight.device_stats()["device_bytes"] < gpu.device_stats()["device_bytes"]
+    finally:
+        tight.close()
+
+
 def test_dropping_unreachable_deposits_changes_nothing(gpu):
     """Deposits with no HitPoint in the 27 cells around them are not stored (most of them in the open tunnel of
     the teapot scene).  A context that keeps them all (SPPM_DEP_FILTER=0) sees the same pairs: equal counters and
