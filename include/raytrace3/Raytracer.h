@@ -181,6 +181,7 @@ struct HitPoint {
 };
 
 class RayTracer {
+    int PhotonCnt = 0;                    // photons handed to PhotonTrace so far (raytracer/Raytracer.h:84)
 public:
     Camera* camera = nullptr;
     Scene* scene = nullptr;
@@ -220,6 +221,37 @@ public:
         const int cnt = (int)sppm_host::env_ll("SPPM_ROUNDS", 10000), onetime = (int)sppm_host::env_ll("SPPM_ONETIME", 100);
         dev.check(sppm_photon_pass(dev.ctx, (uint64_t)cnt, (uint32_t)onetime, 0, 0, seed, replica), "sppm_photon_pass");
         dev.check(sppm_film_add(dev.ctx, film), "sppm_film_add");
+    }
+    // One eye path through the library (raytracer/Raytracer.h:296-357): the ray is traced on the GPU from depth `dep` with
+    // weight `wgt` for pixel (x = row, y = column), and the HitPoints it leaves are appended to Hvec, as the reference's
+    // recursion pushes them.  They live on the host only: the photon pass of the GPU works on the HitPoints of GetHitPoint().
+    void ViewTrace(const Ray& ray, int dep, Color wgt, int x, int y) {
+        sppm_host::Device& dev = sppm_host::Device::get(device);
+        std::lock_guard<std::mutex> g(dev.mu);
+        if (!camera || !scene) throw std::runtime_error("RayTracer: camera and scene must be set");
+        dev.ensure_scene(scene->objvec, scene->plvec);
+        const uint32_t pixel = (uint32_t)(x * camera->w + y);
+        const int32_t d = dep;
+        sppm_hitpoint out[16];
+        uint64_t n = 0;
+        dev.check(sppm_view_trace(dev.ctx, 1, ray.org.val, ray.dir.val, &d, wgt.val, &pixel, camera->w, seed, replica, out, 16, &n), "sppm_view_trace");
+        for (uint64_t i = 0; i < n; i++) {
+            const sppm_hitpoint& h = out[i];
+            Hvec.push_back(new HitPoint(Vec3(h.pos[0], h.pos[1], h.pos[2]), Vec3(h.n[0], h.n[1], h.n[2]), Vec3(h.v[0], h.v[1], h.v[2]),
+                                        scene->objvec[h.obj], h.x, h.y, Vec3(h.wgt[0], h.wgt[1], h.wgt[2])));
+        }
+    }
+    // One photon path through the library (raytracer/Raytracer.h:117-209): traced on the GPU from depth `dep` with `flux`, its
+    // diffuse hits gathered into the HitPoints of the last GetHitPoint() there; Hvec is then read back, so that tao / newN of
+    // its HitPoints show the photon as they do in the reference (costly per call: the reference's loop is PhotonMap()).
+    // Photons are numbered in the order of the calls, which selects their roulette and bounce streams.
+    void PhotonTrace(const Ray& ray, int dep, Color flux) {
+        sppm_host::Device& dev = sppm_host::Device::get(device);
+        std::lock_guard<std::mutex> g(dev.mu);
+        const int32_t d = dep;
+        const uint32_t id = (uint32_t)PhotonCnt++;
+        dev.check(sppm_photon_trace(dev.ctx, 1, ray.org.val, ray.dir.val, &d, flux.val, &id, seed, replica), "sppm_photon_trace");
+        fetch_hitpoints(dev);
     }
     void debugHitPoint() {
         cout << "HitPoint:size:" << Hvec.size() << endl;

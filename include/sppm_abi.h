@@ -310,6 +310,23 @@ int sppm_debug_near_collide(sppm_ctx* ctx, uint64_t n, const double* org, const 
 int sppm_near_collide_noalloc(sppm_ctx* ctx, uint64_t n, const double* org, const double* dir,
                               uint64_t seed, uint32_t replica, sppm_collision* out);
 
+/* RayTracer::ViewTrace(ray, dep, wgt, x, y) (raytracer/Raytracer.h:296-357) for n eye rays of the caller's making instead
+ * of Camera::emit's: ray i (org, dir: n x 3 doubles) starts at depth dep[i] (null: 0) with weight wgt[i] (n x 3) for pixel
+ * pixel[i] = row * w + column, whose random streams its Newton solves draw from.  The HitPoints the paths leave are
+ * returned (x = row, y = column, node = position in the path's tree under the given ray); the context's own HitPoints,
+ * those of sppm_eye_pass, are not touched.  At most 2^22 rays per call. */
+int sppm_view_trace(sppm_ctx* ctx, uint64_t n, const double* org, const double* dir, const int32_t* dep, const double* wgt,
+                    const uint32_t* pixel, int32_t w, uint64_t seed, uint32_t replica,
+                    sppm_hitpoint* out, uint64_t cap, uint64_t* n_out);
+
+/* RayTracer::PhotonTrace(ray, dep, flux) (raytracer/Raytracer.h:117-209) for n photons of the caller's making instead of
+ * Light::emit's: photon i starts as the ray (org, dir) at depth dep[i] (null: 0) with flux[i] (n x 3); its roulette and
+ * bounce draws come from the streams of photon index id[i].  The diffuse hits of the paths are gathered into the HitPoints
+ * of the last sppm_eye_pass (tao, newN) exactly as a photon pass gathers its own; sppm_counters::photons does not count
+ * them.  Queued like a photon pass.  At most 2^22 photons per call; refused while the radius update is on. */
+int sppm_photon_trace(sppm_ctx* ctx, uint64_t n, const double* org, const double* dir, const int32_t* dep, const double* flux,
+                      const uint32_t* id, uint64_t seed, uint32_t replica);
+
 /* Parity hook: Bezier3::newton (raytracer/Bezier.h:112-159) for n (ray, patch)
  * pairs; out_tuv receives (t, u, v) or (1e20, 1e20, 1e20). */
 int sppm_debug_newton(sppm_ctx* ctx, uint64_t n, const double* org, const double* dir,

@@ -130,6 +130,11 @@ ABI_SYMBOLS = {
                                             C.c_uint64, C.c_uint32, C.c_void_p]),
     "sppm_debug_photon_deposits": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
                                              C.POINTER(C.c_double), C.c_uint64, C.POINTER(C.c_uint64)]),
+    "sppm_view_trace": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.c_int32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64,
+                                  C.POINTER(C.c_uint64)]),
+    "sppm_photon_trace": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.c_uint64, C.c_uint32]),
     "sppm_debug_newton": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_int32), C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
 }
@@ -296,6 +301,27 @@ class SppmContext:
                                                patch.ctypes.data_as(C.POINTER(C.c_int32)), seed, replica, _dptr(out)),
                     "sppm_debug_newton")
         return out
+
+    def view_trace(self, org, dir, wgt, pixel, w, seed, replica=0, dep=None):
+        """RayTracer::ViewTrace for eye rays of the caller's making; returns the HitPoints they leave."""
+        org = np.ascontiguousarray(org, dtype=np.float64); dir = np.ascontiguousarray(dir, dtype=np.float64)
+        wgt = np.ascontiguousarray(wgt, dtype=np.float64); pixel = np.ascontiguousarray(pixel, dtype=np.uint32)
+        n = org.shape[0]
+        depp = None if dep is None else np.ascontiguousarray(dep, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int32))
+        cap = 15 * n
+        out = np.zeros(cap, dtype=HITPOINT_DTYPE)
+        got = C.c_uint64(0)
+        self._check(self.lib.sppm_view_trace(self._ctx, n, _dptr(org), _dptr(dir), depp, _dptr(wgt), pixel.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                             int(w), seed, replica, out.ctypes.data_as(C.c_void_p), cap, C.byref(got)), "sppm_view_trace")
+        return out[:got.value]
+
+    def photon_trace(self, org, dir, flux, ids, seed, replica=0, dep=None):
+        """RayTracer::PhotonTrace for photons of the caller's making, gathered into the HitPoints of the last eye pass."""
+        org = np.ascontiguousarray(org, dtype=np.float64); dir = np.ascontiguousarray(dir, dtype=np.float64)
+        flux = np.ascontiguousarray(flux, dtype=np.float64); ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        depp = None if dep is None else np.ascontiguousarray(dep, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int32))
+        self._check(self.lib.sppm_photon_trace(self._ctx, org.shape[0], _dptr(org), _dptr(dir), depp, _dptr(flux),
+                                               ids.ctypes.data_as(C.POINTER(C.c_uint32)), seed, replica), "sppm_photon_trace")
 
     def deposits(self, rounds, per_round, seed, replica=0, photon_begin=0, photon_count=1, cap=1 << 20):
         out = np.zeros((cap, 11), dtype=np.float64)

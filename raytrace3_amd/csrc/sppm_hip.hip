@@ -1923,24 +1923,26 @@ static int overflow_code(sppm_ctx* ctx, const DevCounters& dc, bool can_retry_qu
 //     can leave rays queued after that (the refraction branches of Raytracer.h:327-336); then, and in
 //     the non-default modes, the host reads the queue counters and keeps launching until they are empty.
 // *synced is set when the host has waited for the stream (q then holds the final queue state).
+// n_seed > 0: no fresh items; the launch starts from n_seed ray records the caller has put into queue 1 (ctx->park[1],
+// count in the control block), traced with in-wave solves: rays of the caller's own making (sppm_view_trace, sppm_photon_trace).
 static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_first, uint64_t fresh_count, bool has_dual_lobe,
-                     bool need_final_state, QueueState& q, bool* synced) {
+                     bool need_final_state, QueueState& q, bool* synced, uint64_t n_seed = 0) {
     *synced = false;
     // Photons meet a Bezier object at random, a few lanes per wave, and so do eye rays once the pixels are
     // dealt to the waves in a scattered order (TraceParams::pix_mul): solving in place costs less than the
     // extra launches of a park round.  With pixels in row order the rays that meet the object are whole
     // waves, which would serialise 64 solves each while the other waves idle: then they are parked and
     // solved by k_newton (SPPM_EYE_SCATTER=0, or SPPM_PHOTON_COOP=0 for photons).
-    const bool first_coop = ctx->force_coop || ctx->coop_only || (mode == MODE_PHOTON && ctx->photon_coop) || (mode == MODE_EYE && ctx->eye_scatter);
+    const bool first_coop = n_seed > 0 || ctx->force_coop || ctx->coop_only || (mode == MODE_PHOTON && ctx->photon_coop) || (mode == MODE_EYE && ctx->eye_scatter);
     // The ray and task queues are sized by what can reach them.  With in-wave solves nothing is parked for a solve: only
     // the refraction branches of eye paths through a material that both reflects and refracts are queued (as fresh rays),
     // at most one per path vertex, and their queue grows by doubling when a pass overflows it (park_scale; the eye pass
     // retries like it does for the HitPoint buffer).  Parked solves (the non-default modes) can queue every work item
     // with up to 16 patch tasks each.
     const bool branches = mode == MODE_EYE && has_dual_lobe;
-    const uint64_t park_cap = !first_coop ? std::max<uint64_t>(fresh_count, 1u << 16)
-                              : branches  ? std::max<uint64_t>(fresh_count / 4, ctx->branch_queue_min) * ctx->park_scale
-                                          : (1u << 12);
+    const uint64_t park_cap = std::max<uint64_t>(n_seed, !first_coop ? std::max<uint64_t>(fresh_count, 1u << 16)
+                                                         : branches  ? std::max<uint64_t>(std::max(fresh_count, n_seed) / 4, ctx->branch_queue_min) * ctx->park_scale
+                                                                     : (1u << 12));
     const uint64_t task_cap = first_coop ? 16 : 16 * park_cap;
     if (task_cap > 0xffffffffull) return fail(ctx, SPPM_E_CAPACITY, "too many work items for one round");
     HIPCHK(ctx->park[0].reserve(park_cap)); HIPCHK(ctx->park[1].reserve(park_cap));
@@ -1984,8 +1986,8 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
     };
     tp.park_cap = park_cap; tp.task_cap = task_cap;
     const bool legacy = (mode == MODE_PHOTON && !first_coop);   // photons with parked solves: every round looks at the counters
-    if (int rc = set_round(0, true)) return rc;
-    int first_blocks = blocks_for(fresh_count, first_coop);
+    if (int rc = set_round(n_seed > 0 ? 1 : 0, n_seed == 0)) return rc;       // seeds: read queue 1, write queue 0
+    int first_blocks = blocks_for(n_seed > 0 ? n_seed : fresh_count, first_coop);
     if (int rc = launch_trace_mode(ctx, mode, first_coop, first_blocks, tp)) return rc;
     int cur = 0;   // queue written by the last launch
     if (!legacy) {
@@ -2159,6 +2161,31 @@ int sppm_synchronize(sppm_ctx* ctx) {
     return SPPM_OK;
 }
 
+// k_gather + k_gather_split over the grid-sorted deposits [dstart[b], +dlen[b] or to dstart[b + 1]); `over`: the deposits
+// that found their bucket full under direct placement.  fixed_r2: every radius is still INIT_R2.
+static int launch_gather(sppm_ctx* ctx, const uint32_t* dstart, const uint32_t* dlen, const Deposit* over, uint64_t dep_cap, bool fixed_r2) {
+    tic(ctx, PH_GATHER);
+    const uint64_t tiles = (ctx->n_hp + GATHER_TILE - 1) / GATHER_TILE;
+    const int gather_bpc = ctx->gather_blocks_per_cu > 0 ? ctx->gather_blocks_per_cu : (shares_gpu(ctx->device) ? 3 : 5);
+    const int blocks = (int)std::max<uint64_t>(8, std::min<uint64_t>((uint64_t)ctx->num_cu * gather_bpc, ((tiles + 3) / 4 + 7) / 8 * 8));
+    const uint32_t piece_cap = 1u << 20;
+    HIPCHK(ctx->pieces.reserve(piece_cap));
+#define SPPM_LAUNCH_GATHER(FIXED)                                                                                                                        \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<FIXED>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_r2.p,            \
+                       ctx->hp_wgt.p, ctx->hp_tao.p, (uint32_t)ctx->n_hp, dstart, dlen, ctx->sdep.p, ctx->grid, ctx->tile_ctr(), ctx->pieces.p,         \
+                       ctx->scalars() + SC_PIECES, piece_cap, ctx->counters.p);                                                                          \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_split<FIXED>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_r2.p,      \
+                       ctx->hp_wgt.p, ctx->hp_tao.p, (uint32_t)ctx->n_hp, dstart, dlen, ctx->sdep.p, ctx->grid, ctx->pieces.p,                          \
+                       ctx->scalars() + SC_PIECES, piece_cap, ctx->scalars() + SC_NEXT_PIECE, ctx->counters.p, over, ctx->scalars() + SC_OVER,           \
+                       (unsigned long long)dep_cap, ctx->place_over_max.p, ctx->hstart.p)
+    if (fixed_r2) { SPPM_LAUNCH_GATHER(true); } else { SPPM_LAUNCH_GATHER(false); }
+#undef SPPM_LAUNCH_GATHER
+    HIPCHK(hipGetLastError());
+    toc(ctx);
+    ctx->gather_launches++;
+    return SPPM_OK;
+}
+
 int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_t photon_begin, uint64_t photon_count,
                      uint64_t seed, uint32_t replica) {
     if (!ctx) return SPPM_E_INVALID;
@@ -2254,27 +2281,8 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
             toc(ctx);
         }
         if (ctx->n_hp > 0) {
-            tic(ctx, PH_GATHER);
-            const uint64_t tiles = (ctx->n_hp + GATHER_TILE - 1) / GATHER_TILE;
-            const int gather_bpc = ctx->gather_blocks_per_cu > 0 ? ctx->gather_blocks_per_cu : (shares_gpu(ctx->device) ? 3 : 5);
-            const int blocks = (int)std::max<uint64_t>(8, std::min<uint64_t>((uint64_t)ctx->num_cu * gather_bpc, ((tiles + 3) / 4 + 7) / 8 * 8));
-            const uint32_t piece_cap = 1u << 20;
-            HIPCHK(ctx->pieces.reserve(piece_cap));
             // the deposits that found their bucket full (normally a handful) ride along with the pieces
-            const Deposit* over = placed ? (const Deposit*)ctx->dep.p : (const Deposit*)nullptr;
-#define SPPM_LAUNCH_GATHER(FIXED)                                                                                                                        \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<FIXED>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_r2.p,            \
-                       ctx->hp_wgt.p, ctx->hp_tao.p, (uint32_t)ctx->n_hp, dstart, dlen, ctx->sdep.p, ctx->grid, ctx->tile_ctr(), ctx->pieces.p,         \
-                       ctx->scalars() + SC_PIECES, piece_cap, ctx->counters.p);                                                                          \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_split<FIXED>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_r2.p,      \
-                       ctx->hp_wgt.p, ctx->hp_tao.p, (uint32_t)ctx->n_hp, dstart, dlen, ctx->sdep.p, ctx->grid, ctx->pieces.p,                          \
-                       ctx->scalars() + SC_PIECES, piece_cap, ctx->scalars() + SC_NEXT_PIECE, ctx->counters.p, over, ctx->scalars() + SC_OVER,           \
-                       (unsigned long long)dep_cap, ctx->place_over_max.p, ctx->hstart.p)
-            if (!sweeps && !ctx->radii_changed) { SPPM_LAUNCH_GATHER(true); } else { SPPM_LAUNCH_GATHER(false); }
-#undef SPPM_LAUNCH_GATHER
-            HIPCHK(hipGetLastError());
-            toc(ctx);
-            ctx->gather_launches++;
+            if (int rc = launch_gather(ctx, dstart, dlen, placed ? (const Deposit*)ctx->dep.p : (const Deposit*)nullptr, dep_cap, !sweeps && !ctx->radii_changed)) return rc;
             if (sweeps) {
                 hipLaunchKernelGGL(k_hp_update, dim3((unsigned)((ctx->n_hp + 255) / 256)), dim3(256), 0, ctx->stream, ctx->hp_r2.p, ctx->hp_tao.p,
                                    ctx->hp_meta.p, (uint32_t)ctx->n_hp);
@@ -2560,6 +2568,119 @@ int sppm_debug_photon_deposits(sppm_ctx* ctx, uint64_t rounds, uint32_t per_roun
     }
     *n = real;
     return real <= cap ? SPPM_OK : SPPM_E_CAPACITY;
+}
+
+// Ray records of the caller's making, uploaded as the seed queue of run_trace (queue 1).
+static int upload_seed_rays(sppm_ctx* ctx, uint64_t n, const double* org, const double* dir, const int32_t* dep, const double* carry, const uint32_t* id) {
+    std::vector<ParkRec> recs((size_t)n);
+    for (uint64_t i = 0; i < n; i++) {
+        ParkRec& r = recs[(size_t)i];
+        memset(&r, 0, sizeof(r));
+        for (int k = 0; k < 3; k++) { r.o[k] = org[3 * i + k]; r.d[k] = dir[3 * i + k]; r.carry[k] = (float)carry[3 * i + k]; }
+        r.id = id[i]; r.dep = dep ? dep[i] : 0; r.node = 0; r.aobj = -1;
+    }
+    HIPCHK(ctx->park[1].reserve(std::max<uint64_t>(n, 1u << 12)));
+    HIPCHK(hipMemcpyAsync(ctx->park[1].p, recs.data(), (size_t)n * sizeof(ParkRec), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));     // recs goes out of scope
+    return SPPM_OK;
+}
+
+int sppm_view_trace(sppm_ctx* ctx, uint64_t n, const double* org, const double* dir, const int32_t* dep, const double* wgt,
+                    const uint32_t* pixel, int32_t w, uint64_t seed, uint32_t replica, sppm_hitpoint* out, uint64_t cap, uint64_t* n_out) {
+    if (!ctx || !org || !dir || !wgt || !pixel || !n_out || (!out && cap)) return SPPM_E_INVALID;
+    *n_out = 0;
+    if (!ctx->have_scene) return fail(ctx, SPPM_E_INVALID, "sppm_set_scene must come first");
+    if (w <= 0) return fail(ctx, SPPM_E_INVALID, "image width must be positive");
+    if (n == 0) return SPPM_OK;
+    if (n > (1u << 22)) return fail(ctx, SPPM_E_INVALID, "at most 2^22 rays per call");
+    for (uint64_t i = 0; i < n; i++) if (dep && (dep[i] < 0 || dep[i] > SPPM_MAX_DEP + 1)) return fail(ctx, SPPM_E_INVALID, "depth out of range");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (int rc = check_deferred(ctx)) return rc;
+    if (int rc = upload_seed_rays(ctx, n, org, dir, dep, wgt, pixel)) return rc;
+    // the HitPoints land in the raw array of the eye pass (free between passes); their histogram goes to a throw-away table
+    uint64_t hit_cap = (SPPM_MAX_DEP + 1) * n + dep_slack(ctx, n);
+    DevBuf<uint32_t> sink; DevBuf<DevCounters> tallies;
+    int rc = SPPM_OK;
+    QueueState q{};
+    do {
+        if (ctx->raw.reserve(hit_cap) != hipSuccess || sink.reserve(1u << 16) != hipSuccess || tallies.reserve(1) != hipSuccess) { rc = fail(ctx, SPPM_E_NOMEM, "hipMalloc failed"); break; }
+        if ((rc = launch_pass_reset(ctx, false, nullptr, 0)) != SPPM_OK) break;
+        if ((rc = launch_fill(ctx, (uint32_t*)tallies.p, sizeof(DevCounters) / 4, 0u)) != SPPM_OK) break;
+        if ((rc = launch_fill(ctx, (uint32_t*)(ctx->scalars() + SC_PARK1), 1, (uint32_t)n)) != SPPM_OK) break;
+        TraceParams tp{};
+        tp.hcount = sink.p; tp.grid.inv_cs = 1.0; tp.grid.mask = 0xffffu;
+        tp.w = w; tp.h = 1; tp.pix_mul = 1; tp.npx_magic = ~0ull; tp.w_magic = 0xffffffffu;
+        tp.hits = ctx->raw.p; tp.n_hits = ctx->scalars() + SC_HITS; tp.hit_cap = hit_cap;
+        tp.n_real_hits = ctx->scalars() + SC_REAL_HITS;
+        tp.counters = tallies.p;
+        tp.wave_chunks = ctx->wave_chunks();
+        tp.rng = host_rng_base(seed, replica * 4u + D_EYE);
+        DevCounters* saved = ctx->counters.p;
+        ctx->counters.p = tallies.p;             // the trace driver reads the overflow bits of the counters in use
+        bool synced = false;
+        rc = run_trace(ctx, MODE_EYE, tp, 0, 0, ctx->has_dual_lobe, true, q, &synced, n);
+        ctx->counters.p = saved;
+        if (rc != SPPM_OK) { if (rc > 0) rc = fail(ctx, SPPM_E_CAPACITY, "a queue overflowed while tracing the given rays"); break; }
+        if ((rc = close_chunks(ctx, nullptr, ctx->raw.p, hit_cap)) != SPPM_OK) break;
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { rc = fail(ctx, SPPM_E_DEVICE, hipGetErrorString(e)); break; }
+        const uint64_t claimed = std::min<uint64_t>(q.sc[SC_HITS], hit_cap);
+        std::vector<RawHit> raw((size_t)claimed);
+        if (claimed && hipMemcpy(raw.data(), ctx->raw.p, (size_t)claimed * sizeof(RawHit), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ctx, SPPM_E_DEVICE, "copy of the HitPoints failed"); break; }
+        uint64_t real = 0;
+        for (const RawHit& h : raw) {
+            if (h.pix < 0) continue;
+            if (real < cap) {
+                sppm_hitpoint& o = out[real];
+                memset(&o, 0, sizeof(o));
+                for (int k = 0; k < 3; k++) { o.pos[k] = h.pos[k]; o.n[k] = h.n[k]; o.v[k] = h.v[k]; o.wgt[k] = h.wgt[k]; }
+                o.R2 = SPPM_INIT_R2; o.obj = h.obj; o.x = h.pix / w; o.y = h.pix % w; o.node = h.node; o.N = ctx->initial_n; o.newN = 0;
+            }
+            real++;
+        }
+        *n_out = real;
+        if (real > cap) rc = fail(ctx, SPPM_E_CAPACITY, "the caller's HitPoint array is too small");
+    } while (0);
+    sink.release(); tallies.release();
+    ctx->check_pending = false;
+    return rc;
+}
+
+int sppm_photon_trace(sppm_ctx* ctx, uint64_t n, const double* org, const double* dir, const int32_t* dep, const double* flux,
+                      const uint32_t* id, uint64_t seed, uint32_t replica) {
+    if (!ctx || !org || !dir || !flux || !id) return SPPM_E_INVALID;
+    if (!ctx->have_eye) return fail(ctx, SPPM_E_INVALID, "sppm_eye_pass must come first");
+    if (ctx->initial_n > 0) return fail(ctx, SPPM_E_INVALID, "single photons are not traced with the radius update on");
+    if (n == 0) return SPPM_OK;
+    if (n > (1u << 22)) return fail(ctx, SPPM_E_INVALID, "at most 2^22 photons per call");
+    for (uint64_t i = 0; i < n; i++) if (dep && (dep[i] < 0 || dep[i] > SPPM_MAX_DEP + 1)) return fail(ctx, SPPM_E_INVALID, "depth out of range");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (int rc = check_deferred(ctx)) return rc;
+    if (int rc = upload_seed_rays(ctx, n, org, dir, dep, flux, id)) return rc;
+    const uint32_t M = ctx->grid.mask + 1;
+    const uint64_t dep_cap = (SPPM_MAX_DEP + 1) * n + dep_slack(ctx, n);
+    HIPCHK(ctx->dep.reserve(dep_cap)); HIPCHK(ctx->sdep.reserve(std::max<uint64_t>(dep_cap, ctx->place_valid ? ctx->place_total : 0)));
+    HIPCHK(ctx->place_over_max.reserve(1));
+    TraceParams tp{};
+    fill_photon_params(ctx, tp, 1, dep_cap, seed, replica, ctx->counters.p);
+    if (int rc = launch_pass_reset(ctx, false, ctx->cursor(), 2 * ((size_t)M + 1))) return rc;      // + cursor, dcount
+    if (int rc = launch_fill(ctx, (uint32_t*)(ctx->scalars() + SC_PARK1), 1, (uint32_t)n)) return rc;
+    QueueState q{};
+    bool synced = false;
+    tic(ctx, PH_TRACE);
+    int rc = run_trace(ctx, MODE_PHOTON, tp, 0, 0, false, false, q, &synced, n);
+    toc(ctx);
+    if (rc != SPPM_OK) return rc > 0 ? fail(ctx, SPPM_E_CAPACITY, "a queue overflowed while tracing the given photons") : rc;
+    tic(ctx, PH_SORT);
+    if (int rc2 = launch_scan(ctx, ctx->dcount(), ctx->dstart.p, M, ctx->dep.p, nullptr, dep_cap)) return rc2;   // + chunk tails -> holes
+    hipLaunchKernelGGL(k_dep_scatter, dim3(ctx->num_cu * ctx->scatter_blocks_per_cu), dim3(256), 0, ctx->stream, ctx->dep.p, ctx->scalars() + SC_DEP,
+                       dep_cap, ctx->dstart.p, ctx->cursor(), ctx->sdep.p);
+    HIPCHK(hipGetLastError());
+    toc(ctx);
+    if (ctx->n_hp > 0)
+        if (int rc2 = launch_gather(ctx, ctx->dstart.p, nullptr, nullptr, dep_cap, !ctx->radii_changed)) return rc2;
+    if (ctx->last_rounds == 0) { ctx->last_rounds = 1; ctx->last_per_round = 1; }     // a resolve with nothing but such photons: tao / (PI R2)
+    return SPPM_OK;
 }
 
 int sppm_debug_newton(sppm_ctx* ctx, uint64_t n, const double* org, const double* dir, const int32_t* patch, uint64_t seed,

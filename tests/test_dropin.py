@@ -64,6 +64,20 @@ def test_cpp_host_matches_python_host_and_oracle(tmp_path):
         assert (diff <= 1e-3).mean() >= 0.995 and diff.mean() <= 1e-4
 
 
+@pytest.mark.gpu
+def test_view_trace_and_photon_trace_members():
+    """RayTracer::ViewTrace / PhotonTrace (raytracer/Raytracer.h:296, :117) one path per call from a C++ host: every eye path
+    of a small image by ViewTrace leaves the HitPoints GetHitPoint() leaves, photons of Light::emit sent through PhotonTrace
+    show up in the HitPoints' newN / tao."""
+    from raytrace3_amd import scenes
+    exe = os.path.join(ROOT, "examples", "_build", "trace_members")
+    env = dict(os.environ, SPPM_SEED="11", SPPM_DATA_DIR=scenes.DATA_DIR)
+    r = subprocess.run([exe, os.path.join(scenes.DATA_DIR, "cornell_teapot.scene"), "24", "18", "48"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "OK " in r.stdout and "432 hitpoints" in r.stdout or "OK " in r.stdout
+
+
 def _read_ppm(path):
     with open(path, "rb") as f:
         assert f.readline().strip() == b"P6"

@@ -500,3 +500,63 @@ def test_context_on_the_callers_stream():
         assert np.allclose(g.resolve(), want, rtol=2e-4, atol=1e-6 * want.mean())
     finally:
         g.close()
+
+
+def test_view_trace_and_photon_trace_of_single_paths(gpu):
+    """RayTracer::ViewTrace / PhotonTrace (Raytracer.h:296-357, :117-209) for rays the caller makes: the camera's own rays
+    through sppm_view_trace give the HitPoints of the eye pass; the pass's own photons (emission redone on the host from
+    the same counter streams, Light::emit + Vec3::GetUnitRandVec) through sppm_photon_trace leave every HitPoint the
+    photon count and flux the photon pass leaves."""
+    scene, cam = scenes.scene_teapot(1), scenes.default_camera(40, 30)
+    lib = ol.load()
+    gpu.set_scene(scene)
+    gpu.eye_pass(cam, SEED, 1)
+    want = gpu.hitpoints()
+    want = want[np.argsort(_key(want))]
+    org, d, pix = [], [], []
+    o3, d3 = np.zeros(3), np.zeros(3)
+    for row in range(cam.h):
+        for col in range(cam.w):
+            lib.oracle_camera_emit(cam, row, col, ol.dp(o3), ol.dp(d3))
+            org.append(o3.copy()); d.append(d3.copy()); pix.append(row * cam.w + col)
+    got = gpu.view_trace(np.array(org), np.array(d), np.ones((len(pix), 3)), pix, cam.w, SEED, 1)
+    got = got[np.argsort(_key(got))]
+    assert len(got) == len(want) > 1000 and np.array_equal(_key(got), _key(want)) and np.array_equal(got["obj"], want["obj"])
+    assert np.allclose(got["pos"], want["pos"], rtol=1e-12, atol=1e-7)         # the host normalises the direction its own way
+    assert np.allclose(got["wgt"], want["wgt"], rtol=1e-6, atol=1e-7)
+    # a ray that starts deeper in its path and with another weight: depth limit and weight are honoured
+    deep = gpu.view_trace(np.array(org[:64]), np.array(d[:64]), np.full((64, 3), 0.5), pix[:64], cam.w, SEED, 1, dep=np.full(64, 14))
+    assert len(deep) == 0 or (deep["node"] == 0).all()       # MAX_DEP reached: nothing is followed further
+    half = gpu.view_trace(np.array(org[:64]), np.array(d[:64]), np.full((64, 3), 0.5), pix[:64], cam.w, SEED, 1)
+    full = got[np.isin(_key(got), _key(half))]
+    half = half[np.argsort(_key(half))]
+    assert len(half) > 0 and np.allclose(half["wgt"], 0.5 * full["wgt"], rtol=1e-6, atol=1e-9)
+    assert np.array_equal(_key(gpu.hitpoints()[np.argsort(_key(gpu.hitpoints()))]), _key(want))     # the context's own HitPoints stand
+
+    # ---- photons
+    rounds, per_round = 30, 100
+    n = rounds * per_round
+    gpu.photon_pass(rounds, per_round, SEED, 1)
+    ref = gpu.hitpoints()
+    ref = ref[np.argsort(_key(ref))]
+    c_ref = gpu.counters()
+    light = scene.light_list[0]
+    lpos, lflux = np.array(light[0], dtype=np.float64), np.array(light[1], dtype=np.float64) * 3.1415926 * 4
+    dirs = np.zeros((n, 3))
+    stream = 1 * 4 + 1                                       # replica * 4 + photon domain
+    for g in range(n):
+        for k in range(64):
+            v = np.array([(lib.oracle_rng_u32(SEED, stream, g, 0, 3 * k + a) >> 8) / 16777216.0 * 2.0 - 1.0 for a in range(3)])
+            m = float(v @ v)
+            if not (m > 1 or m < 1e-4):
+                break
+        dirs[g] = v / np.sqrt(m)
+    gpu.eye_pass(cam, SEED, 1)
+    for a, b in ((0, 1000), (1000, 1001), (1001, n)):        # in three calls, one of a single photon
+        gpu.photon_trace(np.tile(lpos, (b - a, 1)), dirs[a:b], np.tile(lflux, (b - a, 1)), np.arange(a, b), SEED, 1)
+    hp = gpu.hitpoints()
+    hp = hp[np.argsort(_key(hp))]
+    assert np.array_equal(hp["newN"], ref["newN"]) and ref["newN"].sum() > 200
+    assert np.allclose(hp["tao"], ref["tao"], rtol=2e-4, atol=1e-6 * ref["tao"].mean())
+    c = gpu.counters()
+    assert all(c[k] == c_ref[k] for k in ("segments", "deposits", "candidates", "accepted")), (c, c_ref)
