@@ -67,6 +67,71 @@ def test_two_rank_sharded_iteration_matches_single_process(tmp_path):
     assert np.allclose(reduced, full, rtol=1e-12, atol=1e-15)
 
 
+# ------------------------------------------------------------------ the host logic of bench.py's loop, on the CPU
+class _HostContext:
+    """The methods sharded_iteration uses, over the CPU oracle: resolve_device writes the float image where the given
+    pointer says (a CPU tensor's storage here), synchronize is a no-op.  What is exercised is the host logic: shard
+    bounds, the empty shard, the whole-pass normaliser, the reduction through host copies (via_host)."""
+
+    def __init__(self, oracle):
+        self.o = oracle
+        self.calls = []
+
+    def eye_pass(self, cam, seed, replica=0):
+        self.o.eye_pass(cam, seed, replica)
+
+    def photon_pass(self, rounds, per_round, seed, replica=0, photon_begin=0, photon_count=0):
+        self.calls.append((photon_begin, photon_count))
+        self.o.photon_pass(rounds, per_round, seed, replica, photon_begin=photon_begin, photon_count=photon_count)
+
+    def resolve_device(self, ptr):
+        import ctypes
+        pic = self.o.resolve().astype(np.float32)
+        ctypes.memmove(ptr, pic.ctypes.data, pic.nbytes)
+
+    def synchronize(self):
+        self.calls.append("sync")
+
+
+def _host_logic_worker(rank, world, port, out_path, rounds, per_round):
+    from tests import oracle_lib as ol
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene, cam = scenes.scene_spheres_plane(True), scenes.default_camera(20, 16)
+    o = ol.OracleContext()
+    o.set_scene(scene)
+    ctx = _HostContext(o)
+    pic = torch.zeros((16, 20, 3), dtype=torch.float32)
+    D.sharded_iteration(ctx, cam, SEED, 0, rounds, per_round, 1, rank, world, pic_tensor=pic, via_host=True)
+    begin, count = D.photon_shard(rounds * per_round, rank, world)
+    # an empty shard still runs a (zero-length) pass, so that the resolve has the normaliser of the whole pass
+    assert ctx.calls[0] == ((begin, count) if count > 0 else (rounds * per_round, 1)) and "sync" in ctx.calls
+    if rank == 0:
+        np.save(out_path, pic.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rounds,per_round", [(21, 100), (1, 2)])
+def test_three_rank_host_logic_with_an_uneven_and_an_empty_shard(tmp_path, rounds, per_round):
+    """Three ranks: 2 100 photons split 700 / 700 / 700, and 2 photons split 1 / 1 / 0 (the third rank's shard is
+    empty).  The partial float images, each resolved with the normaliser of the whole pass and reduced through host copies
+    as ranks that share a GPU do, sum to the single-rank image."""
+    from tests import oracle_lib as ol
+    ol.load()
+    out = str(tmp_path / "pic3.npy")
+    mp.spawn(_host_logic_worker, args=(3, _free_port(), out, rounds, per_round), nprocs=3, join=True)
+    reduced = np.load(out)
+    o = ol.OracleContext()
+    o.set_scene(scenes.scene_spheres_plane(True))
+    o.eye_pass(scenes.default_camera(20, 16), SEED, 0)
+    o.photon_pass(rounds, per_round, SEED, 0)
+    full = o.resolve()
+    assert np.allclose(reduced, full.astype(np.float32), rtol=1e-5, atol=1e-7 * max(full.mean(), 1e-30))
+    if rounds > 1:
+        assert full.sum() > 0
+
+
 # ------------------------------------------------------------------ the same through the HIP path
 def _gpu_worker(rank, world, port, out_path):
     """Two processes share the one GPU of the box; each traces its photon shard through libsppm_hip.so and
