@@ -41,9 +41,9 @@ for config, rounds in (() if GPU_ONLY else (("c1_spheres_plane_256", 1000), ("c2
         r["sample_rounds"], r["full_rounds"] = rounds, full_rounds
         out["cpu"][f"{config}/{threads}"] = r
         print(config, threads, r, flush=True)
-for config in ("c1_spheres_plane_256", "c2_teapot_800x600", "c4_teapot4_1080p", "c5_caustic_1024"):
+for config in ("c1_spheres_plane_256", "c2_teapot_800x600", "c3_teapot_800x600_10M", "c4_teapot4_1080p", "c5_caustic_1024"):
     for key, extra in (("gpu", []), ("gpu_single_stream", ["--inflight", "1"])):
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "100", "--warmup", "10", "--no-cpu-baseline"] + extra,
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "20" if config.startswith(("c3", "c5")) else "100", "--warmup", "10", "--no-cpu-baseline"] + extra,
                            capture_output=True, text=True, timeout=600)
         line = [l for l in p.stdout.splitlines() if l.startswith("{")]
         out[key][config] = json.loads(line[-1]) if line else {"error": p.stderr[-500:]}
