@@ -165,7 +165,7 @@ const char* sppm_last_error(const sppm_ctx* ctx);
  * Scene::NearCollide (raytracer/Scene.h:165-182); patch and object AABBs are
  * rebuilt as Bezier3::read / Bezier3Obj do (raytracer/Bezier.h:167-175, :226-231).
  * Waits for the passes still queued on the context.  Scene tables of up to
- * 64 KiB (224 B per object + 244 B per Bezier patch; the reference's scene: 9
+ * 64 KiB (240 B per object + 244 B per Bezier patch; the reference's scene: 9
  * objects, 32 patches, 10 KiB) are staged in LDS by the kernels, larger ones are
  * read from global memory.  Every patch is also cut into 4 x 4 sub-patches whose
  * boxes (384 B per patch) let the kernels skip solves that cannot find anything;
