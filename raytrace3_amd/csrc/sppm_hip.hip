@@ -995,11 +995,11 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
                         const double vx = hx - ax[r], vy = hy - ay[r], vz = hz - az[r];
                         const double d2 = vx * vx + vy * vy + vz * vz;
                         const bool c = d2 < SPPM_INIT_R2;      // flann radiusSearch(radius = searchR2): strict '<' on the squared distance
+                        // ballots of the bare compares, combined as scalars (a ballot of their conjunction costs two more vector instructions)
+                        const uint64_t cm = __builtin_amdgcn_ballot_w64(c);
                         const float dn = nx * bnx[r] + ny * bny[r] + nz * bnz[r];
                         const bool facing = dn > 1e-3f, inr = FIXED_R2 ? true : (d2 <= R2);
                         const bool ok = c & facing & inr;
-                        // ballots of the bare compares, combined as scalars (a ballot of their conjunction costs two more vector instructions)
-                        const uint64_t cm = __builtin_amdgcn_ballot_w64(c);
                         cand += (uint32_t)__popcll(cm);
                         pn += FIXED_R2 ? (uint32_t)__popcll(cm & __builtin_amdgcn_ballot_w64(facing))
                                        : (uint32_t)__popcll(cm & __builtin_amdgcn_ballot_w64(facing) & __builtin_amdgcn_ballot_w64(inr));

@@ -560,3 +560,36 @@ def test_view_trace_and_photon_trace_of_single_paths(gpu):
     assert np.allclose(hp["tao"], ref["tao"], rtol=2e-4, atol=1e-6 * ref["tao"].mean())
     c = gpu.counters()
     assert all(c[k] == c_ref[k] for k in ("segments", "deposits", "candidates", "accepted")), (c, c_ref)
+
+
+def test_single_photons_between_passes_leave_the_next_pass_alone(gpu):
+    """A context that has laid out its deposit buffer over several passes (deposits written in place), then traced a few
+    photons of the caller's through sppm_photon_trace (which sorts its deposits the other way, into the same buffers),
+    runs its next pass as a context that never did: same HitPoints, tallies and flux sums."""
+    scene, cam = scenes.scene_teapot(1), scenes.default_camera(96, 72)
+    gpu.set_scene(scene)
+    for it in range(3):
+        gpu.eye_pass(cam, SEED, it)
+        gpu.photon_pass(200, 100, SEED, it)
+    light = scene.light_list[0]
+    rng = np.random.default_rng(5)
+    d = rng.normal(size=(300, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    gpu.photon_trace(np.tile(np.array(light[0], dtype=np.float64), (300, 1)), d, np.tile(np.array(light[1], dtype=np.float64), (300, 1)),
+                     np.arange(300), SEED, 9)
+    gpu.eye_pass(cam, SEED, 3)
+    gpu.photon_pass(200, 100, SEED, 3)
+    got, c_got = gpu.hitpoints(), gpu.counters()
+    from raytrace3_amd import SppmContext
+    fresh = SppmContext(0)
+    try:
+        fresh.set_scene(scene)
+        fresh.eye_pass(cam, SEED, 3)
+        fresh.photon_pass(200, 100, SEED, 3)
+        want, c_want = fresh.hitpoints(), fresh.counters()
+    finally:
+        fresh.close()
+    got, want = got[np.argsort(_key(got))], want[np.argsort(_key(want))]
+    assert np.array_equal(_key(got), _key(want)) and np.array_equal(got["newN"], want["newN"]) and want["newN"].sum() > 10000
+    assert np.allclose(got["tao"], want["tao"], rtol=2e-4, atol=1e-6 * want["tao"].mean())
+    assert all(c_got[k] == c_want[k] for k in ("segments", "deposits", "candidates", "accepted")), (c_got, c_want)
