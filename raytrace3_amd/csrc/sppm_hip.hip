@@ -1109,28 +1109,47 @@ __device__ __forceinline__ void gather_overflow(const Deposit* __restrict__ over
     for (unsigned long long i = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n; i += n_waves) {
         const PosKey a = over[i].a;
         const DepB b = over[i].b;
-        for (int c = 0; c < 27; c++) {
-            const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
-            const uint64_t key = a.key + ((uint64_t)(int64_t)dx << 42) + ((uint64_t)(int64_t)dy << 21) + (uint64_t)(int64_t)dz;
-            const uint32_t bk = key_bucket(key, g.mask);
-            const uint32_t s = hstart[bk], e = hstart[bk + 1];
-            for (uint32_t h = s + (uint32_t)lane; h < e; h += 64) {
-                const PosKey hp = hp_pos[h];
-                if (hp.key != key) continue;                    // another cell hashed into this bucket
-                const double vx = hp.x - a.x, vy = hp.y - a.y, vz = hp.z - a.z;
-                const double d2 = vx * vx + vy * vy + vz * vz;
-                if (!(d2 < SPPM_INIT_R2)) continue;
-                cand++;
-                const float4 nr = hp_nr[h];
-                if (!(nr.x * b.nx + nr.y * b.ny + nr.z * b.nz > 1e-3f) || !(d2 <= hp_r2[h])) continue;
-                acc++;
-                const float4 w = hp_wgt[h];
-                float* t = (float*)&hp_tao[h];
-                atomicAdd(t + 0, w.x * (b.fr * (float)SPPM_PI_INV));
-                atomicAdd(t + 1, w.y * (b.fg * (float)SPPM_PI_INV));
-                atomicAdd(t + 2, w.z * (b.fb * (float)SPPM_PI_INV));
-                atomicAdd((int*)(t + 3), 1);
+        // lanes 0..26 look up the HitPoint ranges of the 27 cells together (one round of loads instead of 27 in a row); the
+        // ranges, laid end to end, are then walked 64 HitPoints at a time
+        uint32_t hs = 0, hl = 0;
+        uint64_t ck = 0;
+        if (lane < 27) {
+            const int dx = lane % 3 - 1, dy = (lane / 3) % 3 - 1, dz = lane / 9 - 1;
+            ck = a.key + ((uint64_t)(int64_t)dx << 42) + ((uint64_t)(int64_t)dy << 21) + (uint64_t)(int64_t)dz;
+            const uint32_t bk = key_bucket(ck, g.mask);
+            hs = hstart[bk];
+            hl = hstart[bk + 1] - hs;
+        }
+        const uint64_t cells = __ballot(hl > 0);
+        uint32_t total = 0;
+        for (uint64_t q = cells; q; q &= q - 1) total += bcast_u(hl, __ffsll((unsigned long long)q) - 1);
+        for (uint32_t f0 = 0; f0 < total; f0 += 64) {
+            const uint32_t f = f0 + (uint32_t)lane;
+            uint32_t h = 0, klo = 0, khi = 0, fs = 0;
+            bool in = false;
+            for (uint64_t q = cells; q; q &= q - 1) {       // which range holds flat entry f
+                const int k = __ffsll((unsigned long long)q) - 1;
+                const uint32_t len = bcast_u(hl, k), start = bcast_u(hs, k);
+                const uint32_t lo = bcast_u((uint32_t)ck, k), hi = bcast_u((uint32_t)(ck >> 32), k);
+                if (f >= fs && f < fs + len) { h = start + (f - fs); klo = lo; khi = hi; in = true; }
+                fs += len;
             }
+            if (!in) continue;
+            const PosKey hp = hp_pos[h];
+            if (hp.key != (((uint64_t)khi << 32) | klo)) continue;   // another cell hashed into this bucket
+            const double vx = hp.x - a.x, vy = hp.y - a.y, vz = hp.z - a.z;
+            const double d2 = vx * vx + vy * vy + vz * vz;
+            if (!(d2 < SPPM_INIT_R2)) continue;
+            cand++;
+            const float4 nr = hp_nr[h];
+            if (!(nr.x * b.nx + nr.y * b.ny + nr.z * b.nz > 1e-3f) || !(d2 <= hp_r2[h])) continue;
+            acc++;
+            const float4 w = hp_wgt[h];
+            float* t = (float*)&hp_tao[h];
+            atomicAdd(t + 0, w.x * (b.fr * (float)SPPM_PI_INV));
+            atomicAdd(t + 1, w.y * (b.fg * (float)SPPM_PI_INV));
+            atomicAdd(t + 2, w.z * (b.fb * (float)SPPM_PI_INV));
+            atomicAdd((int*)(t + 3), 1);
         }
     }
     if (cand) atomicAdd(&counters->candidates, cand);
@@ -1170,17 +1189,20 @@ __global__ void __launch_bounds__(256) k_gather_split(const PosKey* __restrict__
 }
 
 // Room per bucket for direct placement, from the histogram of ALL diffuse hits of a batch, reachable by a HitPoint
-// or not: which buckets are reachable changes with every camera jitter (HitPoints seen through the mirrors move far),
-// where the photons land does not.  Room = the count plus a margin that a Poisson count of the same mean all but
-// never exceeds; a bucket without a hit still gets a few slots (far down the open tunnel every batch hits other
-// cells, one photon each).  slack_sigma = 0 leaves no margin at all (tests use it to send deposits down the
-// overflow path).
-__global__ void k_bucket_room(const uint32_t* __restrict__ count, uint32_t n, float slack_sigma, uint32_t slack_add, uint32_t slack_empty,
-                              uint32_t* __restrict__ room) {
+// or not: which buckets are reachable changes with every camera jitter, where the photons land does not.
+// A bucket some HitPoint reaches now (occ) gets the count plus a margin that a Poisson count of the same mean all but
+// never exceeds, and a few slots if it had no hit (far down the open tunnel every batch hits other cells, one photon
+// each).  A bucket out of reach stores nothing as long as it stays so: it gets the count and the small margin `far`
+// (one slot if it had no hit), enough for the buckets at the rim of the HitPoints' reach that a jitter brings in; what
+// does not fit goes to the overflow list either way.  slack_sigma = 0 leaves no margin at all (tests use it to send
+// deposits down the overflow path).
+__global__ void k_bucket_room(const uint32_t* __restrict__ count, const uint8_t* __restrict__ occ, uint32_t n, float slack_sigma, uint32_t slack_add,
+                              uint32_t slack_empty, float far_sigma, uint32_t far_add, uint32_t far_empty, uint32_t* __restrict__ room) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t c = count[i];
-    room[i] = c ? c + (uint32_t)ceilf(slack_sigma * sqrtf((float)c)) + slack_add : slack_empty;
+    if (!occ || occ[i]) room[i] = c ? c + (uint32_t)ceilf(slack_sigma * sqrtf((float)c)) + slack_add : slack_empty;
+    else room[i] = c ? c + (uint32_t)ceilf(far_sigma * sqrtf((float)c)) + far_add : far_empty;
 }
 
 // ------------------------------------------------------------------ resolve (Raytracer.h:281-293)
@@ -1399,6 +1421,7 @@ struct sppm_ctx {
     uint32_t* dcount_all() const { return hcount() + 3 * ((size_t)grid.mask + 2); }
     bool dep_filter = true;               // deposits no HitPoint can reach are not stored (SPPM_DEP_FILTER=0 keeps them)
     bool has_dual_lobe = false;           // some material reflects and refracts: eye paths branch
+    bool one_hp_per_pixel = false;        // no material both stores a HitPoint and sends the eye path on, none branches: a pixel leaves one HitPoint at most
     DevBuf<PosKey> hp_pos; DevBuf<float4> hp_nr, hp_wgt, hp_tao; DevBuf<HpMeta> hp_meta; DevBuf<double> hp_r2;
     bool radii_changed = false;           // an update() sweep has run on the HitPoints of the last eye pass: R2 != INIT_R2 for some
     int initial_n = 0;                    // HitPoint::N at creation (the reference: 0, which keeps update() from ever running)
@@ -1416,6 +1439,7 @@ struct sppm_ctx {
     // 5, 4, 4: 14.1 M / 1 000 (no measurable cost); 4, 8, 2 or 6, 4, 2: 14.2 M / 5 200 (gather + 4 %); 4, 4, 1: 11.4 M / 14 000 (+ 9 %).
     float place_sigma = 5.0f; uint32_t place_add = 4;
     uint32_t place_empty = 4;
+    float place_far_sigma = 1.0f; uint32_t place_far_add = 1, place_far_empty = 1;   // margins of the buckets no HitPoint reaches when the layout is made; sigma < 0: as the others
     bool place_valid = false;
     uint32_t place_M = 0; uint64_t place_photons = 0, place_total = 0;
     DevBuf<uint32_t> place_room, place_start;
@@ -1547,6 +1571,9 @@ int sppm_create(sppm_ctx** out, int device_id) {
     if (const char* b = getenv("SPPM_PLACE_SIGMA")) { ctx->place_sigma = std::max(0.0f, (float)atof(b)); if (ctx->place_sigma == 0.0f) ctx->place_add = 0; }
     if (const char* b = getenv("SPPM_PLACE_ADD")) ctx->place_add = (uint32_t)std::max(0, atoi(b));
     if (const char* b = getenv("SPPM_PLACE_EMPTY")) ctx->place_empty = (uint32_t)std::max(0, atoi(b));
+    if (const char* b = getenv("SPPM_PLACE_FAR_SIGMA")) ctx->place_far_sigma = (float)atof(b);
+    if (const char* b = getenv("SPPM_PLACE_FAR_ADD")) ctx->place_far_add = (uint32_t)std::max(0, atoi(b));
+    if (const char* b = getenv("SPPM_PLACE_FAR_EMPTY")) ctx->place_far_empty = (uint32_t)std::max(0, atoi(b));
     if (const char* b = getenv("SPPM_BRANCH_QUEUE_MIN")) ctx->branch_queue_min = (uint64_t)std::max(1, atoi(b));
     if (const char* b = getenv("SPPM_DEP_PER_PHOTON")) ctx->dep_per_photon = std::min(14.0, std::max(0.01, atof(b)));
     if (const char* b = getenv("SPPM_VERBOSE")) ctx->verbose = atoi(b) != 0;
@@ -1678,7 +1705,7 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
         total += (size_t)td[t].rows * td[t].cols;
         if (total > (1ull << 30)) return fail(ctx, SPPM_E_CAPACITY, "more than 2^30 texels in one scene");
     }
-    bool dual_lobe = false;
+    bool dual_lobe = false, hp_then_on = false;
     for (int i = 0; i < no; i++) {
         const sppm_object& so = s->objects[i];
         DevObject& o = objs[i];
@@ -1710,6 +1737,7 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
         o.tex_rows = o.tex_cols = 0; o.tex_off = 0;
         if (o.texture >= 0) { o.tex_rows = td[o.texture].rows; o.tex_cols = td[o.texture].cols; o.tex_off = td[o.texture].offset; }
         if ((o.flags & F_REFL) && (o.flags & F_REFR)) dual_lobe = true;
+        if ((o.flags & F_DIFF) && (o.flags & (F_REFL | F_REFR))) hp_then_on = true;
         if (so.type == SPPM_OBJ_BEZIER) {
             if (so.first_patch < 0 || so.n_patches < 0 || so.first_patch + so.n_patches > np)
                 return fail(ctx, SPPM_E_INVALID, "bezier object indexes patches out of range");
@@ -1772,6 +1800,7 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
     HIPCHK(hipMemcpy(ctx->lights.p, dl.data(), dl.size() * sizeof(DevLight), hipMemcpyHostToDevice));
     ctx->n_lights = s->n_lights;
     ctx->has_dual_lobe = dual_lobe;
+    ctx->one_hp_per_pixel = !dual_lobe && !hp_then_on;
     ctx->place_valid = false;
     ctx->have_scene = true;
     ctx->have_eye = false;
@@ -2030,7 +2059,9 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
     ctx->cam = *cam;
     ctx->have_eye = false;
     const uint64_t npx = (uint64_t)cam->w * cam->h;
-    uint64_t hit_cap = std::max<uint64_t>(2 * npx, 1 << 16) + dep_slack(ctx, npx);
+    // raw HitPoint slots: what the pixels can leave if that is known (the reference's scene: one each), else a guess that
+    // the retry below doubles
+    uint64_t hit_cap = std::max<uint64_t>(ctx->one_hp_per_pixel ? npx : 2 * npx, 1 << 16) + dep_slack(ctx, npx);
     if (!ctx->accumulate_stats) drop_spans(ctx);
     // ---- the hashed grid the HitPoints will be sorted into.  The eye kernel histograms them as it writes them, so the
     // bucket count is chosen BEFORE the trace, from the HitPoint count of the last eye pass at this resolution (a
@@ -2212,7 +2243,10 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
     // overflows them is traced again with more (below); a placed batch only uses this buffer as its overflow list.
     auto cap_for = [&](double per_photon) { return (uint64_t)std::ceil((double)batch * std::min<double>(per_photon, SPPM_MAX_DEP + 1)) + dep_slack(ctx, batch); };
     uint64_t dep_cap = cap_for(ctx->dep_per_photon);
-    HIPCHK(ctx->dep.reserve(dep_cap)); HIPCHK(ctx->sdep.reserve(std::max<uint64_t>(dep_cap, ctx->place_valid ? ctx->place_total : 0)));
+    // The buffer of deposits as traced is reserved batch by batch: a counting-sorted batch needs dep_cap slots of it, a
+    // placed one only an overflow list.
+    const uint64_t over_room = std::max<uint64_t>(1u << 16, batch / 4);
+    HIPCHK(ctx->sdep.reserve(std::max<uint64_t>(dep_cap, ctx->place_valid ? ctx->place_total : 0)));
     HIPCHK(ctx->place_over_max.reserve(1));
     TraceParams tp{};
     fill_photon_params(ctx, tp, per_round, dep_cap, seed, replica, ctx->counters.p);
@@ -2226,17 +2260,21 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
         bool lay_out = false;     // this batch is counting-sorted and leaves a layout behind
         const uint32_t* dstart = placed ? ctx->place_start.p : ctx->dstart.p;
         const uint32_t* dlen = placed ? ctx->dcount() : nullptr;
+        uint64_t over_cap = 0;
         if (placed) {
             if (int rc = launch_pass_reset(ctx, false, ctx->dcount(), (size_t)M + 1)) return rc;
             tp.place = ctx->place_start.p; tp.sorted = ctx->sdep.p; tp.dcount_all = nullptr;
-            // the overflow list is the buffer the counting sort would have read: it holds every deposit of a batch if it must
-            tp.over = ctx->dep.p; tp.n_over = ctx->scalars() + SC_OVER; tp.over_cap = dep_cap;
+            // the overflow list lives in the buffer the counting sort reads (all of it, if that is still there)
+            HIPCHK(ctx->dep.reserve(over_room));
+            over_cap = ctx->dep.n;
+            tp.over = ctx->dep.p; tp.n_over = ctx->scalars() + SC_OVER; tp.over_cap = over_cap;
             tic(ctx, PH_TRACE);
             bool synced = false;
             if (int rc = run_trace(ctx, MODE_PHOTON, tp, first, count, false, false, q, &synced)) return rc;
             toc(ctx);
         } else {
-            tp.place = nullptr;
+            HIPCHK(ctx->dep.reserve(dep_cap));
+            fill_photon_params(ctx, tp, per_round, dep_cap, seed, replica, ctx->counters.p);
             lay_out = ctx->place_enabled && ctx->dep_filter && !sweeps && ctx->n_hp > 0 && count == batch;
             tp.dcount_all = lay_out ? ctx->dcount_all() : nullptr;
             DevCounters first_failed{};
@@ -2282,7 +2320,8 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
         }
         if (ctx->n_hp > 0) {
             // the deposits that found their bucket full (normally a handful) ride along with the pieces
-            if (int rc = launch_gather(ctx, dstart, dlen, placed ? (const Deposit*)ctx->dep.p : (const Deposit*)nullptr, dep_cap, !sweeps && !ctx->radii_changed)) return rc;
+            if (int rc = launch_gather(ctx, dstart, dlen, placed ? (const Deposit*)ctx->dep.p : (const Deposit*)nullptr, placed ? over_cap : dep_cap,
+                                       !sweeps && !ctx->radii_changed)) return rc;
             if (sweeps) {
                 hipLaunchKernelGGL(k_hp_update, dim3((unsigned)((ctx->n_hp + 255) / 256)), dim3(256), 0, ctx->stream, ctx->hp_r2.p, ctx->hp_tao.p,
                                    ctx->hp_meta.p, (uint32_t)ctx->n_hp);
@@ -2294,8 +2333,10 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
         // (one wait for the stream, for the total; later batches and passes of this size are placed directly).
         if (lay_out) {
             HIPCHK(ctx->place_room.reserve((size_t)M + 1)); HIPCHK(ctx->place_start.reserve((size_t)M + 1));
-            hipLaunchKernelGGL(k_bucket_room, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, ctx->dcount_all(), M, ctx->place_sigma,
-                               ctx->place_add, ctx->place_add ? ctx->place_empty : 0u, ctx->place_room.p);
+            const bool far = ctx->place_far_sigma >= 0.0f && ctx->place_sigma > 0.0f;
+            hipLaunchKernelGGL(k_bucket_room, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, ctx->dcount_all(), far ? (const uint8_t*)ctx->occ() : (const uint8_t*)nullptr,
+                               M, ctx->place_sigma, ctx->place_add, ctx->place_add ? ctx->place_empty : 0u, ctx->place_far_sigma, ctx->place_far_add,
+                               ctx->place_far_empty, ctx->place_room.p);
             HIPCHK(hipGetLastError());
             if (int rc = launch_scan(ctx, ctx->place_room.p, ctx->place_start.p, M)) return rc;
             uint32_t total_room = 0;
@@ -2305,6 +2346,9 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
             ctx->place_total = total_room; ctx->place_M = M; ctx->place_photons = count; ctx->place_valid = true;
             HIPCHK(ctx->sdep.reserve(std::max<uint64_t>(dep_cap, ctx->place_total)));
             tp.sorted = ctx->sdep.p;
+            // the batches to come are placed: the counting sort's input buffer goes back (the stream is idle), an overflow
+            // list takes its place; a batch that has to be counting-sorted again reserves it anew
+            if (ctx->dep.n > over_room) ctx->dep.release();
         }
     }
     return SPPM_OK;   // queued; a queue overflow, if any, is reported by the next call that waits for the stream

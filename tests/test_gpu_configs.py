@@ -540,14 +540,16 @@ def _same_pass(a, b):
     assert np.allclose(ha["tao"], hb["tao"], rtol=1e-4, atol=1e-6 * ha["tao"].mean())
 
 
-@pytest.mark.parametrize("sigma", [None, "0"])
-def test_direct_placement_matches_the_counting_sort(sigma):
+@pytest.mark.parametrize("sigma,far", [(None, None), (None, "-1"), ("0", None)])
+def test_direct_placement_matches_the_counting_sort(sigma, far):
     """After one counting-sorted batch a context places the deposits of later batches of that size straight into
     per-bucket room laid out from that batch's histogram; deposits that find their bucket full are gathered from the
     deposit's side.  Every pass equals the one of a context that always sorts (SPPM_PLACE=0): same counters, same
     per-HitPoint photon counts.  With SPPM_PLACE_SIGMA=0 the room is the old count exactly, so a good part of the
     deposits takes the overflow path.  A camera turned round sees other HitPoints and keeps other deposits; the layout,
-    made from every diffuse hit, serves it as well."""
+    made from every diffuse hit, serves it as well: with the same margins everywhere (SPPM_PLACE_FAR_SIGMA=-1) for good,
+    by default (small margins for the buckets out of reach when the layout was made) through the overflow list, until
+    the context lays the room out anew."""
     scene = scenes.scene_teapot(1)
     cam, cam_far = scenes.default_camera(120, 90), scenes.look_at((50, 40, 140), (50, 38, 900), 120, 90)   # turned round, down the open end of the tunnel
     env = {"SPPM_PLACE": "0"}
@@ -558,10 +560,13 @@ def test_direct_placement_matches_the_counting_sort(sigma):
         del os.environ["SPPM_PLACE"]
     if sigma is not None:
         os.environ["SPPM_PLACE_SIGMA"] = sigma
+    if far is not None:
+        os.environ["SPPM_PLACE_FAR_SIGMA"] = far
     try:
         ctx = SppmContext(0)
     finally:
         os.environ.pop("SPPM_PLACE_SIGMA", None)
+        os.environ.pop("SPPM_PLACE_FAR_SIGMA", None)
     try:
         ref.set_scene(scene)
         ctx.set_scene(scene)
@@ -570,9 +575,11 @@ def test_direct_placement_matches_the_counting_sort(sigma):
             a = _pass_state(ctx, c, 400, replica)
             sorts.append(a[2]["deposit_sort_ms"] > 0)
             _same_pass(a, _pass_state(ref, c, 400, replica))
-        assert sorts[0] and not sorts[1]                 # the first pass lays the room out, the second is placed
+        assert sorts[0] and not sorts[1]                    # the first pass lays the room out, the second is placed
         if sigma is None:
-            # the layout is made from where the photons land, not from what the camera sees: it outlives the turn
+            assert not sorts[2] and not sorts[3]            # ... and so are the third and the first one after the turn
+        if sigma is None and far == "-1":
+            # a layout made from where the photons land alone, not from what the camera sees, outlives the turn
             assert sorts == [True, False, False, False, False, False], sorts
         # a larger batch than the layout was made for is counting-sorted again
         a = _pass_state(ctx, cam, 800, 9)
