@@ -2333,16 +2333,22 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
         // (one wait for the stream, for the total; later batches and passes of this size are placed directly).
         if (lay_out) {
             HIPCHK(ctx->place_room.reserve((size_t)M + 1)); HIPCHK(ctx->place_start.reserve((size_t)M + 1));
-            const bool far = ctx->place_far_sigma >= 0.0f && ctx->place_sigma > 0.0f;
-            hipLaunchKernelGGL(k_bucket_room, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, ctx->dcount_all(), far ? (const uint8_t*)ctx->occ() : (const uint8_t*)nullptr,
-                               M, ctx->place_sigma, ctx->place_add, ctx->place_add ? ctx->place_empty : 0u, ctx->place_far_sigma, ctx->place_far_add,
-                               ctx->place_far_empty, ctx->place_room.p);
-            HIPCHK(hipGetLastError());
-            if (int rc = launch_scan(ctx, ctx->place_room.p, ctx->place_start.p, M)) return rc;
+            // First with the full margin for every bucket; if that room is more than the buffer of sorted deposits holds
+            // anyway (it is as large as the buffer of deposits as traced), again with the small margins for the buckets out
+            // of the HitPoints' reach: the tighter layout sends more deposits to the overflow list and is only worth its memory.
             uint32_t total_room = 0;
             HIPCHK(hipMemsetAsync(ctx->place_over_max.p, 0, sizeof(unsigned long long), ctx->stream));
-            HIPCHK(hipMemcpyAsync(&total_room, ctx->place_start.p + M, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));
+            for (int tight = 0; tight < 2; tight++) {
+                hipLaunchKernelGGL(k_bucket_room, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, ctx->dcount_all(),
+                                   tight ? (const uint8_t*)ctx->occ() : (const uint8_t*)nullptr, M, ctx->place_sigma, ctx->place_add,
+                                   ctx->place_add ? ctx->place_empty : 0u, ctx->place_far_sigma, ctx->place_far_add, ctx->place_far_empty, ctx->place_room.p);
+                HIPCHK(hipGetLastError());
+                if (int rc = launch_scan(ctx, ctx->place_room.p, ctx->place_start.p, M)) return rc;
+                HIPCHK(hipMemcpyAsync(&total_room, ctx->place_start.p + M, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                const bool may_tighten = ctx->place_far_sigma >= 0.0f && ctx->place_sigma > 0.0f;
+                if (tight || !may_tighten || total_room <= std::max<uint64_t>(dep_cap, ctx->sdep.n)) break;
+            }
             ctx->place_total = total_room; ctx->place_M = M; ctx->place_photons = count; ctx->place_valid = true;
             HIPCHK(ctx->sdep.reserve(std::max<uint64_t>(dep_cap, ctx->place_total)));
             tp.sorted = ctx->sdep.p;
