@@ -42,15 +42,18 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (spec)
 SEED = 20260101
 
 
-def cpu_baseline(scene, w, h, rounds, threads):
+def cpu_baseline(scene, w, h, rounds, threads, literal=True):
     """The reference's CPU path as restated by the oracle (fp64, global MWC stream, kd-tree
     radius search + the per-round update() sweep), `threads` replicas in parallel like the
     reference's `omp parallel for num_threads(4)`.  Bounded sample: full-resolution eye pass,
-    `rounds` x 100 photons per replica."""
+    `rounds` x 100 photons per replica.
+    literal=False: the same restatement with a hashed-grid gather in place of the kd-tree and without the
+    per-round update() sweep over all HitPoints (a guarded no-op in the reference that is most of its CPU
+    time): what the host cores do when they do not pay for that sweep."""
     from raytrace3_amd import scenes
     from tests import oracle_lib as ol
     lib = ol.load()
-    ctxs = [ol.OracleContext(lib, rng_literal=True) for _ in range(threads)]
+    ctxs = [ol.OracleContext(lib, rng_literal=literal) for _ in range(threads)]
     rng = np.random.default_rng(1)
     cams = []
     for _ in range(threads):
@@ -69,15 +72,16 @@ def cpu_baseline(scene, w, h, rounds, threads):
         return time.perf_counter() - t0
 
     t_eye = run(lambda i: ctxs[i].eye_pass(cams[i], SEED, i))
-    t_ph = run(lambda i: ctxs[i].photon_pass(rounds, 100, SEED, i, mode=ol.GATHER_KDTREE))
+    t_ph = run(lambda i: ctxs[i].photon_pass(rounds, 100, SEED, i, mode=ol.GATHER_KDTREE if literal else ol.GATHER_GRID))
     photons = threads * rounds * 100
     for c in ctxs:
         c.close()
     return {
         "value": photons / t_ph / 1e6, "unit": "Mphotons/s", "cores": threads, "kind": "port", "host_nproc": os.cpu_count(),
         "sample": f"{threads} replicas x {rounds * 100} photons ({rounds} rounds x 100) on the {w}x{h} teapot scene, "
-                  f"photon pass {t_ph:.1f} s (eye pass {t_eye:.1f} s not counted), oracle literal mode: fp64, kd-tree "
-                  f"radius search, per-round update() sweep",
+                  f"photon pass {t_ph:.1f} s (eye pass {t_eye:.1f} s not counted), "
+                  + ("oracle literal mode: fp64, kd-tree radius search, per-round update() sweep" if literal else
+                     "oracle with a hashed-grid gather and no per-round update() sweep: fp64, counter-based random streams"),
         "eye_pass_s": t_eye, "photon_pass_s": t_ph,
     }
 
@@ -355,6 +359,10 @@ def main():
             if cores > 4:
                 allc = cpu_baseline(scene, w, h, max(1, args.cpu_rounds * 4 // cores), cores)
                 base["all_cores"] = {k: allc[k] for k in ("value", "unit", "cores", "sample")}
+            # ... and without the sweep that the reference pays for nothing: the baseline a CPU implementation free of it sets
+            # (a larger sample: its fixed cost, the grid over the HitPoints, would weigh on a short one)
+            tuned = cpu_baseline(scene, w, h, args.cpu_rounds * 2, cores, literal=False)
+            base["all_cores_grid_gather_no_update_sweep"] = {k: tuned[k] for k in ("value", "unit", "cores", "sample")}
             out["cpu_baseline"] = base
         print(json.dumps(out), flush=True)
     for c in ctxs:

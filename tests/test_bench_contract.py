@@ -56,6 +56,8 @@ def test_bench_line_keeps_the_contract():
     assert c["host_nproc"] >= 1
     if "all_cores" in c:
         assert c["all_cores"]["cores"] > 4 and c["all_cores"]["value"] > 0
+    t = c["all_cores_grid_gather_no_update_sweep"]     # the restatement without the reference's dead sweep: the fairer CPU figure
+    assert t["value"] > 0 and t["cores"] >= 1 and "no per-round update() sweep" in t["sample"]
     k = d["kernel_ms_per_step_one_in_flight"]
     assert all(k[x] >= 0 for x in ("eye_trace_ms", "grid_build_ms", "photon_trace_ms", "deposit_sort_ms", "gather_ms", "resolve_ms"))
     assert d["counters_per_step"]["photons"] == 1_000_000
