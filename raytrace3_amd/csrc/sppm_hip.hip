@@ -1156,9 +1156,10 @@ __device__ __forceinline__ void gather_overflow(const Deposit* __restrict__ over
     if (acc) atomicAdd(&counters->accepted, acc);
 }
 
-// The queued pieces of heavy cells (see GATHER_SPLIT_ROWS), one wave per piece at a time.
+// The queued pieces of heavy cells (see GATHER_SPLIT_ROWS), one wave per piece at a time.  Held to 80 registers (a few
+// values spill) like k_gather, so that three of its workgroups fit a CU's register files beside a trace workgroup.
 template <bool FIXED_R2>
-__global__ void __launch_bounds__(256) k_gather_split(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
+__global__ void __launch_bounds__(256, 6) k_gather_split(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
                                                       const double* __restrict__ hp_r2, const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
                                                       const uint32_t* __restrict__ dstart, const uint32_t* __restrict__ dlen,
                                                       const Deposit* __restrict__ deps, GridParams g,
