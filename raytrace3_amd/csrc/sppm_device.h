@@ -400,42 +400,41 @@ __device__ __forceinline__ f3 patch_point(const float* P, float u, float v) {
 
 // The patch in the form the Newton solver evaluates: S(u,v) - c = sum_j sum_i Q[j][i] u^i v^j, the bicubic
 // of Bezier.h:69-111 expanded from the Bernstein to the power basis around the patch centre c (done once per
-// scene on the host, in fp64).  Horner evaluation of S, dS/du, dS/dv costs ~115 fp32 operations instead of
-// ~160 in Bernstein form, and coordinates relative to the centre are a few units instead of ~100, so the fp32
-// residual org + dir t - S(u,v) is formed from small numbers.  Q: 48 wave-uniform values (SGPRs).
+// scene on the host, in fp64).  Coordinates relative to the centre are a few units instead of ~100, so the fp32
+// residual org + dir t - S(u,v) is formed from small numbers.  Q: 48 wave-uniform values.
+// Every polynomial in Horner form, the derivatives as q1 + 2u (q2 + 1.5u q3): 3 + 2 fused operations per (row, coordinate)
+// and 3 + 3 + 2 per coordinate, 96 in all for S, dS/du, dS/dv (~160 in Bernstein form).
 __device__ __forceinline__ void patch_eval_pw(const float* Q, float u, float v, f3& S, f3& Su, f3& Sv) {
-    const float u2 = u * u, u3 = u2 * u, w1 = 2.0f * u, w2 = 3.0f * u2;
-    const float x1 = 2.0f * v, x2 = 3.0f * v * v;
+    const float ua = 1.5f * u, ub = 2.0f * u, va = 1.5f * v, vb = 2.0f * v;
     float A[4][3], D[4][3];
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const float q0 = Q[(j * 4 + 0) * 3 + c], q1 = Q[(j * 4 + 1) * 3 + c], q2 = Q[(j * 4 + 2) * 3 + c], q3 = Q[(j * 4 + 3) * 3 + c];
-            A[j][c] = q0 + (q1 * u + (q2 * u2 + q3 * u3));
-            D[j][c] = q1 + (q2 * w1 + q3 * w2);
+            A[j][c] = fmaf(fmaf(fmaf(q3, u, q2), u, q1), u, q0);
+            D[j][c] = fmaf(fmaf(q3, ua, q2), ub, q1);
         }
     float s[3], su[3], sv[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        s[c] = A[0][c] + v * (A[1][c] + v * (A[2][c] + v * A[3][c]));
-        su[c] = D[0][c] + v * (D[1][c] + v * (D[2][c] + v * D[3][c]));
-        sv[c] = A[1][c] + (x1 * A[2][c] + x2 * A[3][c]);
+        s[c] = fmaf(fmaf(fmaf(A[3][c], v, A[2][c]), v, A[1][c]), v, A[0][c]);
+        su[c] = fmaf(fmaf(fmaf(D[3][c], v, D[2][c]), v, D[1][c]), v, D[0][c]);
+        sv[c] = fmaf(fmaf(A[3][c], va, A[2][c]), vb, A[1][c]);
     }
     S = {s[0], s[1], s[2]}; Su = {su[0], su[1], su[2]}; Sv = {sv[0], sv[1], sv[2]};
 }
 __device__ __forceinline__ f3 patch_point_pw(const float* Q, float u, float v) {
-    const float u2 = u * u, u3 = u2 * u;
     float A[4][3];
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int c = 0; c < 3; c++)
-            A[j][c] = Q[(j * 4 + 0) * 3 + c] + (Q[(j * 4 + 1) * 3 + c] * u + (Q[(j * 4 + 2) * 3 + c] * u2 + Q[(j * 4 + 3) * 3 + c] * u3));
+            A[j][c] = fmaf(fmaf(fmaf(Q[(j * 4 + 3) * 3 + c], u, Q[(j * 4 + 2) * 3 + c]), u, Q[(j * 4 + 1) * 3 + c]), u, Q[(j * 4 + 0) * 3 + c]);
     f3 S;
-    S.x = A[0][0] + v * (A[1][0] + v * (A[2][0] + v * A[3][0]));
-    S.y = A[0][1] + v * (A[1][1] + v * (A[2][1] + v * A[3][1]));
-    S.z = A[0][2] + v * (A[1][2] + v * (A[2][2] + v * A[3][2]));
+    S.x = fmaf(fmaf(fmaf(A[3][0], v, A[2][0]), v, A[1][0]), v, A[0][0]);
+    S.y = fmaf(fmaf(fmaf(A[3][1], v, A[2][1]), v, A[1][1]), v, A[0][1]);
+    S.z = fmaf(fmaf(fmaf(A[3][2], v, A[2][2]), v, A[1][2]), v, A[0][2]);
     return S;
 }
 
@@ -458,11 +457,12 @@ __device__ __forceinline__ void newton_restart(const float* Q, f3 o, f3 d, float
             }
         }
         // columns a = d, b = -Su, c = -Sv; inverse rows = (b x c, c x a, a x b) / det; det == 0 -> zero matrix
+        // (the other two rows as triple products of r x d, one cross product fewer, were measured slower)
         float c0x = Su.y * Sv.z - Su.z * Sv.y, c0y = Su.z * Sv.x - Su.x * Sv.z, c0z = Su.x * Sv.y - Su.y * Sv.x;  // b x c
         float c1x = d.y * Sv.z - d.z * Sv.y, c1y = d.z * Sv.x - d.x * Sv.z, c1z = d.x * Sv.y - d.y * Sv.x;        // c x a = d x Sv
         float c2x = Su.y * d.z - Su.z * d.y, c2y = Su.z * d.x - Su.x * d.z, c2z = Su.x * d.y - Su.y * d.x;        // a x b = Su x d
         float det = d.x * c0x + d.y * c0y + d.z * c0z;
-        float inv = (det == 0.0f) ? 0.0f : 1.0f / det;
+        float inv = (det == 0.0f) ? 0.0f : __builtin_amdgcn_rcpf(det);   // the hardware's reciprocal (1 ulp): a Newton step does not need the division's last bit
         t -= (c0x * rx + c0y * ry + c0z * rz) * inv;
         u -= (c1x * rx + c1y * ry + c1z * rz) * inv;
         v -= (c2x * rx + c2y * ry + c2z * rz) * inv;
