@@ -1156,10 +1156,11 @@ __device__ __forceinline__ void gather_overflow(const Deposit* __restrict__ over
     if (acc) atomicAdd(&counters->accepted, acc);
 }
 
-// The queued pieces of heavy cells (see GATHER_SPLIT_ROWS), one wave per piece at a time.  Held to 80 registers (a few
-// values spill) like k_gather, so that three of its workgroups fit a CU's register files beside a trace workgroup.
-template <bool FIXED_R2>
-__global__ void __launch_bounds__(256, 6) k_gather_split(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
+// The queued pieces of heavy cells (see GATHER_SPLIT_ROWS), one wave per piece at a time.  SHARE: held to 80 registers (a
+// few values spill) like k_gather, so that three of its workgroups fit a CU's register files beside a trace workgroup:
+// the variant for contexts that share their GPU; a context that is alone launches the one that spills nothing.
+template <bool FIXED_R2, bool SHARE>
+__global__ void __launch_bounds__(256, SHARE ? 6 : 1) k_gather_split(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
                                                       const double* __restrict__ hp_r2, const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
                                                       const uint32_t* __restrict__ dstart, const uint32_t* __restrict__ dlen,
                                                       const Deposit* __restrict__ deps, GridParams g,
@@ -2202,15 +2203,17 @@ static int launch_gather(sppm_ctx* ctx, const uint32_t* dstart, const uint32_t* 
     const int blocks = (int)std::max<uint64_t>(8, std::min<uint64_t>((uint64_t)ctx->num_cu * gather_bpc, ((tiles + 3) / 4 + 7) / 8 * 8));
     const uint32_t piece_cap = 1u << 20;
     HIPCHK(ctx->pieces.reserve(piece_cap));
-#define SPPM_LAUNCH_GATHER(FIXED)                                                                                                                        \
+#define SPPM_LAUNCH_GATHER(FIXED, SHARE)                                                                                                                        \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<FIXED>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_r2.p,            \
                        ctx->hp_wgt.p, ctx->hp_tao.p, (uint32_t)ctx->n_hp, dstart, dlen, ctx->sdep.p, ctx->grid, ctx->tile_ctr(), ctx->pieces.p,         \
                        ctx->scalars() + SC_PIECES, piece_cap, ctx->counters.p);                                                                          \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_split<FIXED>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_r2.p,      \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_split<FIXED, SHARE>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_r2.p, \
                        ctx->hp_wgt.p, ctx->hp_tao.p, (uint32_t)ctx->n_hp, dstart, dlen, ctx->sdep.p, ctx->grid, ctx->pieces.p,                          \
                        ctx->scalars() + SC_PIECES, piece_cap, ctx->scalars() + SC_NEXT_PIECE, ctx->counters.p, over, ctx->scalars() + SC_OVER,           \
                        (unsigned long long)dep_cap, ctx->place_over_max.p, ctx->hstart.p)
-    if (fixed_r2) { SPPM_LAUNCH_GATHER(true); } else { SPPM_LAUNCH_GATHER(false); }
+    const bool share = shares_gpu(ctx->device);
+    if (fixed_r2) { if (share) { SPPM_LAUNCH_GATHER(true, true); } else { SPPM_LAUNCH_GATHER(true, false); } }
+    else          { if (share) { SPPM_LAUNCH_GATHER(false, true); } else { SPPM_LAUNCH_GATHER(false, false); } }
 #undef SPPM_LAUNCH_GATHER
     HIPCHK(hipGetLastError());
     toc(ctx);
