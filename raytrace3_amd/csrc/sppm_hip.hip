@@ -742,21 +742,32 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_final(const uint32_t* __r
     if (blockIdx.x == nb - 1 && threadIdx.x == 0) start[n] = offset + tile_total;
 }
 
+// A HitPoint lands at a place of the sorted arrays that depends on its bucket: every array written here costs a
+// partly filled memory line per HitPoint.  Only what the gather reads goes this way (position and cell, normal, weight and
+// pixel); the fields every HitPoint starts with alike (R2, tao, newN) are filled in order by k_hp_occupancy, and the
+// ones only a host that asks for the HitPoints (or the radius update) reads are written by k_hp_meta when asked for, through
+// the place noted here in the order of the raw array.
 __global__ void k_hp_scatter(const RawHit* hits, uint32_t n, GridParams g, const uint32_t* start,
-                             uint32_t* cursor, PosKey* hp_pos, float4* hp_nr, float4* hp_wgt, float4* hp_tao, HpMeta* hp_meta,
-                             double* hp_r2, int initial_n) {
+                             uint32_t* cursor, PosKey* hp_pos, float4* hp_nr, float4* hp_wgt, uint32_t* sorted_of_raw) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const RawHit h = hits[i];
-    if (h.pix < 0) return;                              // a claimed but unused slot
+    if (h.pix < 0) { sorted_of_raw[i] = 0xffffffffu; return; }   // a claimed but unused slot
     PosKey pk; pk.x = h.pos[0]; pk.y = h.pos[1]; pk.z = h.pos[2]; pk.key = cell_key(ld3(h.pos), g.inv_cs);
     const uint32_t b = key_bucket(pk.key, g.mask);
     uint32_t s = start[b] + atomicAdd(&cursor[b], 1u);
     hp_pos[s] = pk;
     hp_nr[s] = make_float4(h.n[0], h.n[1], h.n[2], 0.f);
-    hp_r2[s] = SPPM_INIT_R2;                                                              // HitPoint(): R2 = INIT_R2, Raytracer.h:65
     hp_wgt[s] = make_float4(h.wgt[0], h.wgt[1], h.wgt[2], __int_as_float(h.pix));
-    hp_tao[s] = make_float4(0, 0, 0, __int_as_float(0));                                  // tao = 0, newN = 0
+    sorted_of_raw[i] = s;
+}
+// View direction, tree node, object and N of every HitPoint, in the sorted order (see k_hp_scatter).
+__global__ void k_hp_meta(const RawHit* hits, uint32_t n, const uint32_t* __restrict__ sorted_of_raw, HpMeta* hp_meta, int initial_n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = sorted_of_raw[i];
+    if (s == 0xffffffffu) return;
+    const RawHit h = hits[i];
     HpMeta m; m.v[0] = h.v[0]; m.v[1] = h.v[1]; m.v[2] = h.v[2]; m.node = h.node; m.obj = h.obj; m.N = initial_n;   // HitPoint(): N = 0, Raytracer.h:66
     hp_meta[s] = m;
 }
@@ -765,9 +776,14 @@ __global__ void k_hp_scatter(const RawHit* hits, uint32_t n, GridParams g, const
 // in every direction (the gather of a cell looks at exactly those 27).  One thread per HitPoint of the sorted
 // array; only the first of a run of equal cells does the marking.  A byte per bucket, set by plain stores:
 // neighbouring cells mark the same few buckets over and over, which read-modify-write atomics would serialise.
-__global__ void k_hp_occupancy(const PosKey* __restrict__ hp_pos, uint32_t n, GridParams g, uint8_t* occ) {
+// The same threads give every HitPoint its starting radius and sums (HitPoint(): R2 = INIT_R2, tao = 0, newN = 0,
+// Raytracer.h:65), in order.
+__global__ void k_hp_occupancy(const PosKey* __restrict__ hp_pos, uint32_t n, GridParams g, uint8_t* occ, double* __restrict__ hp_r2,
+                               float4* __restrict__ hp_tao) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    hp_r2[i] = SPPM_INIT_R2;
+    hp_tao[i] = make_float4(0, 0, 0, __int_as_float(0));
     const uint64_t key = hp_pos[i].key;
     if (i > 0 && hp_pos[i - 1].key == key) return;
 #pragma unroll
@@ -1337,6 +1353,9 @@ struct DevBuf {
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    // For sizes that wander from call to call (the HitPoint count moves with the camera jitter): growing a buffer frees
+    // the old one, which waits for every stream of the GPU, so a buffer that must grow grows past what is asked for.
+    hipError_t reserve_with_room(size_t want) { return want <= n ? hipSuccess : reserve(want + want / 16 + 4096); }
 };
 
 uint32_t next_pow2(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
@@ -1425,6 +1444,9 @@ struct sppm_ctx {
     bool has_dual_lobe = false;           // some material reflects and refracts: eye paths branch
     bool one_hp_per_pixel = false;        // no material both stores a HitPoint and sends the eye path on, none branches: a pixel leaves one HitPoint at most
     DevBuf<PosKey> hp_pos; DevBuf<float4> hp_nr, hp_wgt, hp_tao; DevBuf<HpMeta> hp_meta; DevBuf<double> hp_r2;
+    DevBuf<uint32_t> sorted_of_raw;       // place of every raw HitPoint slot in the sorted arrays (0xffffffff: an unused slot)
+    bool meta_valid = false;              // hp_meta holds the HitPoints of the last eye pass (written on demand: ensure_meta)
+    uint64_t raw_claimed = 0;             // slots of the raw array the last eye pass claimed
     bool radii_changed = false;           // an update() sweep has run on the HitPoints of the last eye pass: R2 != INIT_R2 for some
     int initial_n = 0;                    // HitPoint::N at creation (the reference: 0, which keeps update() from ever running)
     uint32_t rounds_per_update = 1;       // with initial_n > 0: rounds of a photon pass between two update() sweeps
@@ -1600,7 +1622,7 @@ void sppm_destroy(sppm_ctx* ctx) {
     ctx->blob.release(); ctx->texels.release(); ctx->lights.release();
     ctx->raw.release(); ctx->park[0].release(); ctx->park[1].release(); ctx->ntask[0].release(); ctx->ntask[1].release(); ctx->nres.release();
     ctx->hist.release(); ctx->hstart.release();
-    ctx->hp_pos.release(); ctx->hp_nr.release(); ctx->hp_wgt.release(); ctx->hp_tao.release(); ctx->hp_meta.release(); ctx->hp_r2.release();
+    ctx->hp_pos.release(); ctx->hp_nr.release(); ctx->hp_wgt.release(); ctx->hp_tao.release(); ctx->hp_meta.release(); ctx->hp_r2.release(); ctx->sorted_of_raw.release();
     ctx->dep.release(); ctx->sdep.release(); ctx->pieces.release();
     ctx->place_room.release(); ctx->place_start.release(); ctx->place_over_max.release();
     ctx->dstart.release(); ctx->scan_partial.release(); ctx->ctl.release(); ctx->counters.release(); ctx->pic.release();
@@ -2053,6 +2075,20 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
 
 extern "C" {
 
+// The HitPoints' view direction, tree node, object and N, which only a host that asks for the HitPoints and the radius
+// update read: written from the raw array of the last eye pass the first time they are wanted (and before anything else
+// reuses that array).
+static int ensure_meta(sppm_ctx* ctx) {
+    if (ctx->meta_valid) return SPPM_OK;
+    if (ctx->raw_claimed > 0) {
+        hipLaunchKernelGGL(k_hp_meta, dim3((unsigned)((ctx->raw_claimed + 255) / 256)), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)ctx->raw_claimed,
+                           ctx->sorted_of_raw.p, ctx->hp_meta.p, ctx->initial_n);
+        HIPCHK(hipGetLastError());
+    }
+    ctx->meta_valid = true;
+    return SPPM_OK;
+}
+
 int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t replica) {
     if (!ctx || !cam) return SPPM_E_INVALID;
     if (!ctx->have_scene) return fail(ctx, SPPM_E_INVALID, "sppm_set_scene must come first");
@@ -2118,18 +2154,23 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
     // ---- counting sort of the HitPoints by bucket (the histogram is the eye kernel's)
     const uint64_t n = ctx->n_hp;
     tic(ctx, PH_GRID);
-    HIPCHK(ctx->hp_pos.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_nr.reserve(std::max<uint64_t>(n, 1)));
-    HIPCHK(ctx->hp_wgt.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_tao.reserve(std::max<uint64_t>(n, 1)));
-    HIPCHK(ctx->hp_meta.reserve(std::max<uint64_t>(n, 1))); HIPCHK(ctx->hp_r2.reserve(std::max<uint64_t>(n, 1)));
+    HIPCHK(ctx->hp_pos.reserve_with_room(n)); HIPCHK(ctx->hp_nr.reserve_with_room(n));
+    HIPCHK(ctx->hp_wgt.reserve_with_room(n)); HIPCHK(ctx->hp_tao.reserve_with_room(n));
+    HIPCHK(ctx->hp_meta.reserve_with_room(n)); HIPCHK(ctx->hp_r2.reserve_with_room(n));
     if (n > 0) {
         const int blocks = (int)((claimed + 255) / 256);
         if (int rc = launch_scan(ctx, ctx->hcount(), ctx->hstart.p, M, nullptr, ctx->raw.p, hit_cap)) return rc;   // + chunk tails -> holes
+        HIPCHK(ctx->sorted_of_raw.reserve(std::max<uint64_t>(hit_cap, 1)));   // as many as the raw array holds: the claimed count wanders with the jitter, and growing a buffer waits for the GPU
         hipLaunchKernelGGL(k_hp_scatter, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)claimed, ctx->grid,
-                           ctx->hstart.p, ctx->cursor(), ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->hp_tao.p, ctx->hp_meta.p,
-                           ctx->hp_r2.p, ctx->initial_n);
-        hipLaunchKernelGGL(k_hp_occupancy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->hp_pos.p, (uint32_t)n, ctx->grid, ctx->occ());
+                           ctx->hstart.p, ctx->cursor(), ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->sorted_of_raw.p);
+        hipLaunchKernelGGL(k_hp_occupancy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->hp_pos.p, (uint32_t)n, ctx->grid, ctx->occ(),
+                           ctx->hp_r2.p, ctx->hp_tao.p);
         HIPCHK(hipGetLastError());
     }
+    ctx->raw_claimed = n > 0 ? claimed : 0;
+    ctx->meta_valid = false;
+    if (ctx->initial_n > 0)                      // the radius update keeps N in the record
+        if (int rc = ensure_meta(ctx)) return rc;
     toc(ctx);
     ctx->have_eye = true;
     ctx->radii_changed = false;
@@ -2179,6 +2220,10 @@ int sppm_set_stream(sppm_ctx* ctx, void* hip_stream) {
 int sppm_set_radius_update(sppm_ctx* ctx, int32_t initial_n, uint32_t rounds_per_update) {
     if (!ctx) return SPPM_E_INVALID;
     if (initial_n < 0 || (initial_n > 0 && rounds_per_update == 0)) return fail(ctx, SPPM_E_INVALID, "initial_n >= 0 and rounds_per_update >= 1");
+    if (ctx->have_eye && initial_n != ctx->initial_n) {   // the HitPoints of the last eye pass keep the N they were made with
+        HIPCHK(hipSetDevice(ctx->device));
+        if (int rc = ensure_meta(ctx)) return rc;
+    }
     ctx->initial_n = initial_n;
     ctx->rounds_per_update = std::max<uint32_t>(1, rounds_per_update);
     return SPPM_OK;
@@ -2412,6 +2457,7 @@ int sppm_get_hitpoints(sppm_ctx* ctx, sppm_hitpoint* out, uint64_t cap, uint64_t
     const uint64_t m = std::min<uint64_t>(cap, ctx->n_hp);
     if (m == 0 || !out) return SPPM_OK;
     HIPCHK(hipSetDevice(ctx->device));
+    if (int rc = ensure_meta(ctx)) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));   // the copies below go through the null stream, which a caller's stream need not wait for
     std::vector<PosKey> pos(m); std::vector<float4> nr(m), wg(m), tao(m); std::vector<HpMeta> meta(m); std::vector<double> r2(m);
     HIPCHK(hipMemcpy(r2.data(), ctx->hp_r2.p, m * sizeof(double), hipMemcpyDeviceToHost));
@@ -2650,6 +2696,7 @@ int sppm_view_trace(sppm_ctx* ctx, uint64_t n, const double* org, const double* 
     for (uint64_t i = 0; i < n; i++) if (dep && (dep[i] < 0 || dep[i] > SPPM_MAX_DEP + 1)) return fail(ctx, SPPM_E_INVALID, "depth out of range");
     HIPCHK(hipSetDevice(ctx->device));
     if (int rc = check_deferred(ctx)) return rc;
+    if (ctx->have_eye) if (int rc = ensure_meta(ctx)) return rc;     // the raw array is about to be reused
     if (int rc = upload_seed_rays(ctx, n, org, dir, dep, wgt, pixel)) return rc;
     // the HitPoints land in the raw array of the eye pass (free between passes); their histogram goes to a throw-away table
     uint64_t hit_cap = (SPPM_MAX_DEP + 1) * n + dep_slack(ctx, n);
