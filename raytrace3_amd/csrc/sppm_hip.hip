@@ -1224,15 +1224,23 @@ __global__ void k_bucket_room(const uint32_t* __restrict__ count, const uint8_t*
 }
 
 // ------------------------------------------------------------------ resolve (Raytracer.h:281-293)
+// ONE_PER_PIXEL: no material of the scene lets a pixel leave more than one HitPoint (the reference's scene), so a pixel's
+// value is its HitPoint's and is stored, not added with atomics.
+template <bool ONE_PER_PIXEL>
 __global__ void k_resolve(const double* hp_r2, const float4* hp_wgt, const float4* hp_tao, uint32_t n_hp, double inv_norm, float* pic) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_hp) return;
     float4 t = hp_tao[i];
     int pix = __float_as_int(hp_wgt[i].w);
     double s = inv_norm / hp_r2[i];   // 1 / PI / (R2 * cnt * onetime)
-    atomicAdd(&pic[3 * (size_t)pix + 0], (float)(t.x * s));
-    atomicAdd(&pic[3 * (size_t)pix + 1], (float)(t.y * s));
-    atomicAdd(&pic[3 * (size_t)pix + 2], (float)(t.z * s));
+    float* p = pic + 3 * (size_t)pix;
+    if (ONE_PER_PIXEL) {
+        p[0] = (float)(t.x * s); p[1] = (float)(t.y * s); p[2] = (float)(t.z * s);
+    } else {
+        atomicAdd(p + 0, (float)(t.x * s));
+        atomicAdd(p + 1, (float)(t.y * s));
+        atomicAdd(p + 2, (float)(t.z * s));
+    }
 }
 
 // ------------------------------------------------------------------ film: image sum and tone-map (Raytracer.h:449-470)
@@ -1924,16 +1932,26 @@ static int launch_trace_mode(sppm_ctx* ctx, int mode, bool coop, int blocks, con
 
 // What the host reads back when it has to look at the queues.
 struct QueueState { unsigned long long sc[CTL_SCALARS]; DevCounters dc; };
+struct QueueLanding { QueueState q; unsigned long long over_max; };
+// The queue scalars, the tallies and the overflow high-water mark, written straight into the host's pinned landing area
+// by one small kernel (three copies of their own were three launches on the stream the host is waiting for).
+__global__ void k_queue_snapshot(const unsigned long long* __restrict__ scalars, const DevCounters* __restrict__ dc,
+                                 const unsigned long long* __restrict__ over_max, QueueLanding* out) {
+    const uint32_t i = threadIdx.x;
+    if (i < CTL_SCALARS) out->q.sc[i] = scalars[i];
+    const uint32_t* src = (const uint32_t*)dc;
+    uint32_t* dst = (uint32_t*)&out->q.dc;
+    for (uint32_t k = i; k < sizeof(DevCounters) / 4; k += blockDim.x) dst[k] = src[k];
+    if (i == 0) out->over_max = over_max ? *over_max : 0ull;
+}
 static int read_queues(sppm_ctx* ctx, QueueState& q) {
-    struct Landing { QueueState q; unsigned long long over_max; };
+    typedef QueueLanding Landing;
     if (!ctx->host_q) HIPCHK(hipHostMalloc(&ctx->host_q, sizeof(Landing), hipHostMallocDefault));
     Landing* L = (Landing*)ctx->host_q;
-    L->over_max = 0;
-    // three small copies queued back to back into pinned memory, one wait
-    HIPCHK(hipMemcpyAsync(L->q.sc, ctx->scalars(), sizeof(L->q.sc), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(&L->q.dc, ctx->counters.p, sizeof(L->q.dc), hipMemcpyDeviceToHost, ctx->stream));
     const bool look = ctx->place_valid && ctx->place_over_max.p;
-    if (look) HIPCHK(hipMemcpyAsync(&L->over_max, ctx->place_over_max.p, sizeof(L->over_max), hipMemcpyDeviceToHost, ctx->stream));
+    hipLaunchKernelGGL(k_queue_snapshot, dim3(1), dim3(64), 0, ctx->stream, ctx->scalars(), ctx->counters.p,
+                       look ? ctx->place_over_max.p : (const unsigned long long*)nullptr, L);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     q = L->q;
     const unsigned long long over_max = L->over_max;
@@ -2420,8 +2438,12 @@ int sppm_resolve_device(sppm_ctx* ctx, float* dev_pic) {
     if (ctx->n_hp > 0) {
         const double inv_norm = 1.0 / SPPM_PI / ((double)ctx->last_rounds * (double)ctx->last_per_round);
         const int blocks = (int)((ctx->n_hp + 255) / 256);
-        hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_r2.p, ctx->hp_wgt.p, ctx->hp_tao.p, (uint32_t)ctx->n_hp,
-                           inv_norm, dev_pic);
+        if (ctx->one_hp_per_pixel)
+            hipLaunchKernelGGL(k_resolve<true>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_r2.p, ctx->hp_wgt.p, ctx->hp_tao.p, (uint32_t)ctx->n_hp,
+                               inv_norm, dev_pic);
+        else
+            hipLaunchKernelGGL(k_resolve<false>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_r2.p, ctx->hp_wgt.p, ctx->hp_tao.p, (uint32_t)ctx->n_hp,
+                               inv_norm, dev_pic);
         HIPCHK(hipGetLastError());
     }
     toc(ctx);
