@@ -742,13 +742,15 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_final(const uint32_t* __r
     if (blockIdx.x == nb - 1 && threadIdx.x == 0) start[n] = offset + tile_total;
 }
 
+// What the gather reads of a HitPoint, one 64-byte record: position and cell, normal, weight and pixel.
+struct HpRec { PosKey a; float4 nr; float4 wgt; };   // nr.w unused; wgt.w: the pixel index (bits of an int)
+static_assert(sizeof(HpRec) == 64, "one memory line per HitPoint");
 // A HitPoint lands at a place of the sorted arrays that depends on its bucket: every array written here costs a
-// partly filled memory line per HitPoint.  Only what the gather reads goes this way (position and cell, normal, weight and
-// pixel); the fields every HitPoint starts with alike (R2, tao, newN) are filled in order by k_hp_occupancy, and the
+// partly filled memory line per HitPoint.  Only the record the gather reads goes this way, as one line; the fields every HitPoint starts with alike (R2, tao, newN) are filled in order by k_hp_occupancy, and the
 // ones only a host that asks for the HitPoints (or the radius update) reads are written by k_hp_meta when asked for, through
 // the place noted here in the order of the raw array.
 __global__ void k_hp_scatter(const RawHit* hits, uint32_t n, GridParams g, const uint32_t* start,
-                             uint32_t* cursor, PosKey* hp_pos, float4* hp_nr, float4* hp_wgt, uint32_t* sorted_of_raw) {
+                             uint32_t* cursor, HpRec* hp, uint32_t* sorted_of_raw) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const RawHit h = hits[i];
@@ -756,9 +758,11 @@ __global__ void k_hp_scatter(const RawHit* hits, uint32_t n, GridParams g, const
     PosKey pk; pk.x = h.pos[0]; pk.y = h.pos[1]; pk.z = h.pos[2]; pk.key = cell_key(ld3(h.pos), g.inv_cs);
     const uint32_t b = key_bucket(pk.key, g.mask);
     uint32_t s = start[b] + atomicAdd(&cursor[b], 1u);
-    hp_pos[s] = pk;
-    hp_nr[s] = make_float4(h.n[0], h.n[1], h.n[2], 0.f);
-    hp_wgt[s] = make_float4(h.wgt[0], h.wgt[1], h.wgt[2], __int_as_float(h.pix));
+    HpRec r;
+    r.a = pk;
+    r.nr = make_float4(h.n[0], h.n[1], h.n[2], 0.f);
+    r.wgt = make_float4(h.wgt[0], h.wgt[1], h.wgt[2], __int_as_float(h.pix));
+    hp[s] = r;
     sorted_of_raw[i] = s;
 }
 // View direction, tree node, object and N of every HitPoint, in the sorted order (see k_hp_scatter).
@@ -778,14 +782,14 @@ __global__ void k_hp_meta(const RawHit* hits, uint32_t n, const uint32_t* __rest
 // neighbouring cells mark the same few buckets over and over, which read-modify-write atomics would serialise.
 // The same threads give every HitPoint its starting radius and sums (HitPoint(): R2 = INIT_R2, tao = 0, newN = 0,
 // Raytracer.h:65), in order.
-__global__ void k_hp_occupancy(const PosKey* __restrict__ hp_pos, uint32_t n, GridParams g, uint8_t* occ, double* __restrict__ hp_r2,
+__global__ void k_hp_occupancy(const HpRec* __restrict__ hp, uint32_t n, GridParams g, uint8_t* occ, double* __restrict__ hp_r2,
                                float4* __restrict__ hp_tao) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     hp_r2[i] = SPPM_INIT_R2;
     hp_tao[i] = make_float4(0, 0, 0, __int_as_float(0));
-    const uint64_t key = hp_pos[i].key;
-    if (i > 0 && hp_pos[i - 1].key == key) return;
+    const uint64_t key = hp[i].a.key;
+    if (i > 0 && hp[i - 1].a.key == key) return;
 #pragma unroll
     for (int c = 0; c < 27; c++) {
         const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
@@ -898,9 +902,9 @@ struct GatherPiece { uint32_t tile_base, lead, row_begin, row_end; };   // lead:
 // FIXED_R2: every HitPoint still has R2 = INIT_R2 (the reference's case: update() never runs), so `dist^2 <= R2` is
 // implied by the search radius test and the radii are not even loaded.
 template <bool PIECE, bool FIXED_R2>
-__device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
+__device__ __forceinline__ void gather_tile(const uint32_t base, const HpRec* __restrict__ hp,
                                             const double* __restrict__ hp_r2,
-                                            const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, const uint32_t n_hp,
+                                            float4* __restrict__ hp_tao, const uint32_t n_hp,
                                             const uint32_t* __restrict__ dstart, const uint32_t* __restrict__ dlen,
                                             const Deposit* __restrict__ deps,
                                             const GridParams g, GatherPiece* __restrict__ pieces, unsigned long long* n_pieces,
@@ -909,10 +913,11 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
     const int lane = lane_id();
     const uint32_t mine = base + lane;
     const bool valid = (uint32_t)lane < GATHER_TILE && mine < n_hp;
-    const PosKey mp = hp_pos[valid ? mine : base];
-    const float4 mnr = hp_nr[valid ? mine : base];
+    const HpRec mrec = hp[valid ? mine : base];
+    const PosKey mp = mrec.a;
+    const float4 mnr = mrec.nr;
     const double mr2 = FIXED_R2 ? SPPM_INIT_R2 : hp_r2[valid ? mine : base];
-    const float4 mw = hp_wgt[valid ? mine : base];
+    const float4 mw = mrec.wgt;
     // Running sums of HitPoint j: its flux in lanes j, 16 + j, 32 + j, 48 + j, one partial sum per DPP row (j < GATHER_TILE <= 16),
     // so that a sweep only reduces inside the rows of 16 lanes (four DPP adds per channel instead of a whole-wave reduction
     // and a broadcast); the four partial sums meet once, when the tile is done.  The count, which comes from ballots, is kept
@@ -1081,8 +1086,8 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const PosKey* _
 // tiles in flight on one XCD are neighbours in bucket order and share its L2, and moves on to the
 // other eighths when its own is drained (tile cost varies with the photon density around it).
 template <bool FIXED_R2>
-__global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
-                                                const double* __restrict__ hp_r2, const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
+__global__ void __launch_bounds__(256) k_gather(const HpRec* __restrict__ hp,
+                                                const double* __restrict__ hp_r2, float4* __restrict__ hp_tao, uint32_t n_hp,
                                                 const uint32_t* __restrict__ dstart, const uint32_t* __restrict__ dlen,
                                                 const Deposit* __restrict__ deps,
                                                 GridParams g, uint32_t* tile_ctr, GatherPiece* __restrict__ pieces,
@@ -1098,7 +1103,7 @@ __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_po
             if (lane_id() == 0) t = atomicAdd(&tile_ctr[q * 16], 1u);
             t = bcast_u(t, 0) + q * per;
             if (t >= q_end) break;
-            gather_tile<false, FIXED_R2>(t * GATHER_TILE, hp_pos, hp_nr, hp_r2, hp_wgt, hp_tao, n_hp, dstart, dlen, deps, g, pieces, n_pieces, piece_cap,
+            gather_tile<false, FIXED_R2>(t * GATHER_TILE, hp, hp_r2, hp_tao, n_hp, dstart, dlen, deps, g, pieces, n_pieces, piece_cap,
                                &counters->overflow, GatherPiece{0, 0, 0, 0}, cand, acc_n, row_tests);
         }
     }
@@ -1113,9 +1118,9 @@ __global__ void __launch_bounds__(256) k_gather(const PosKey* __restrict__ hp_po
 // wave per deposit walks the HitPoints of the 27 cells around it (the HitPoint array is sorted by bucket: hstart).
 // Runs at the end of k_gather_split, whose waves use atomics on the HitPoints as well.
 __device__ __forceinline__ void gather_overflow(const Deposit* __restrict__ over, const unsigned long long* n_over, unsigned long long over_cap,
-                                                unsigned long long* over_max, const uint32_t* __restrict__ hstart, const PosKey* __restrict__ hp_pos,
-                                                const float4* __restrict__ hp_nr, const double* __restrict__ hp_r2,
-                                                const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, GridParams g,
+                                                unsigned long long* over_max, const uint32_t* __restrict__ hstart, const HpRec* __restrict__ hp_rec,
+                                                const double* __restrict__ hp_r2,
+                                                float4* __restrict__ hp_tao, GridParams g,
                                                 DevCounters* counters) {
     const unsigned long long n = min(*n_over, over_cap);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(over_max, n);   // the host drops a layout that overflows much
@@ -1151,16 +1156,16 @@ __device__ __forceinline__ void gather_overflow(const Deposit* __restrict__ over
                 fs += len;
             }
             if (!in) continue;
-            const PosKey hp = hp_pos[h];
+            const PosKey hp = hp_rec[h].a;
             if (hp.key != (((uint64_t)khi << 32) | klo)) continue;   // another cell hashed into this bucket
             const double vx = hp.x - a.x, vy = hp.y - a.y, vz = hp.z - a.z;
             const double d2 = vx * vx + vy * vy + vz * vz;
             if (!(d2 < SPPM_INIT_R2)) continue;
             cand++;
-            const float4 nr = hp_nr[h];
+            const float4 nr = hp_rec[h].nr;
             if (!(nr.x * b.nx + nr.y * b.ny + nr.z * b.nz > 1e-3f) || !(d2 <= hp_r2[h])) continue;
             acc++;
-            const float4 w = hp_wgt[h];
+            const float4 w = hp_rec[h].wgt;
             float* t = (float*)&hp_tao[h];
             atomicAdd(t + 0, w.x * (b.fr * (float)SPPM_PI_INV));
             atomicAdd(t + 1, w.y * (b.fg * (float)SPPM_PI_INV));
@@ -1176,8 +1181,8 @@ __device__ __forceinline__ void gather_overflow(const Deposit* __restrict__ over
 // few values spill) like k_gather, so that three of its workgroups fit a CU's register files beside a trace workgroup:
 // the variant for contexts that share their GPU; a context that is alone launches the one that spills nothing.
 template <bool FIXED_R2, bool SHARE>
-__global__ void __launch_bounds__(256, SHARE ? 6 : 1) k_gather_split(const PosKey* __restrict__ hp_pos, const float4* __restrict__ hp_nr,
-                                                      const double* __restrict__ hp_r2, const float4* __restrict__ hp_wgt, float4* __restrict__ hp_tao, uint32_t n_hp,
+__global__ void __launch_bounds__(256, SHARE ? 6 : 1) k_gather_split(const HpRec* __restrict__ hp,
+                                                      const double* __restrict__ hp_r2, float4* __restrict__ hp_tao, uint32_t n_hp,
                                                       const uint32_t* __restrict__ dstart, const uint32_t* __restrict__ dlen,
                                                       const Deposit* __restrict__ deps, GridParams g,
                                                       const GatherPiece* __restrict__ pieces, const unsigned long long* __restrict__ n_pieces,
@@ -1192,7 +1197,7 @@ __global__ void __launch_bounds__(256, SHARE ? 6 : 1) k_gather_split(const PosKe
     // play (a launch with nothing queued costs no atomic at all)
     for (unsigned long long i = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n;) {
         const GatherPiece pc = pieces[i];
-        gather_tile<true, FIXED_R2>(pc.tile_base, hp_pos, hp_nr, hp_r2, hp_wgt, hp_tao, n_hp, dstart, dlen, deps, g, nullptr, nullptr, 0u, nullptr, pc, cand, acc_n, row_tests);
+        gather_tile<true, FIXED_R2>(pc.tile_base, hp, hp_r2, hp_tao, n_hp, dstart, dlen, deps, g, nullptr, nullptr, 0u, nullptr, pc, cand, acc_n, row_tests);
         if (n <= n_waves) break;
         unsigned long long nx = 0;
         if (lane_id() == 0) nx = atomicAdd(next_piece, 1ull);
@@ -1203,7 +1208,7 @@ __global__ void __launch_bounds__(256, SHARE ? 6 : 1) k_gather_split(const PosKe
         if (acc_n) atomicAdd(&counters->accepted, (unsigned long long)acc_n);
         if (row_tests) atomicAdd(&counters->row_tests, (unsigned long long)row_tests);
     }
-    if (over) gather_overflow(over, n_over, over_cap, over_max, hstart, hp_pos, hp_nr, hp_r2, hp_wgt, hp_tao, g, counters);
+    if (over) gather_overflow(over, n_over, over_cap, over_max, hstart, hp, hp_r2, hp_tao, g, counters);
 }
 
 // Room per bucket for direct placement, from the histogram of ALL diffuse hits of a batch, reachable by a HitPoint
@@ -1227,11 +1232,11 @@ __global__ void k_bucket_room(const uint32_t* __restrict__ count, const uint8_t*
 // ONE_PER_PIXEL: no material of the scene lets a pixel leave more than one HitPoint (the reference's scene), so a pixel's
 // value is its HitPoint's and is stored, not added with atomics.
 template <bool ONE_PER_PIXEL>
-__global__ void k_resolve(const double* hp_r2, const float4* hp_wgt, const float4* hp_tao, uint32_t n_hp, double inv_norm, float* pic) {
+__global__ void k_resolve(const double* hp_r2, const HpRec* hp, const float4* hp_tao, uint32_t n_hp, double inv_norm, float* pic) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_hp) return;
     float4 t = hp_tao[i];
-    int pix = __float_as_int(hp_wgt[i].w);
+    int pix = __float_as_int(hp[i].wgt.w);
     double s = inv_norm / hp_r2[i];   // 1 / PI / (R2 * cnt * onetime)
     float* p = pic + 3 * (size_t)pix;
     if (ONE_PER_PIXEL) {
@@ -1246,12 +1251,12 @@ __global__ void k_resolve(const double* hp_r2, const float4* hp_wgt, const float
 // ------------------------------------------------------------------ film: image sum and tone-map (Raytracer.h:449-470)
 // film += resolve: the image sum of SPPMRayTracer::render (Raytracer.h:449-458) taken straight from the HitPoints, in fp64
 // as the reference's camera.pic.  Contexts on other streams add to the same film, hence the atomics.
-__global__ void k_film_add(const double* hp_r2, const float4* hp_wgt, const float4* hp_tao, uint32_t n_hp, double inv_norm, double* film) {
+__global__ void k_film_add(const double* hp_r2, const HpRec* hp, const float4* hp_tao, uint32_t n_hp, double inv_norm, double* film) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_hp) return;
     float4 t = hp_tao[i];
     if (t.x == 0.f && t.y == 0.f && t.z == 0.f) return;
-    int pix = __float_as_int(hp_wgt[i].w);
+    int pix = __float_as_int(hp[i].wgt.w);
     double s = inv_norm / hp_r2[i];   // 1 / PI / (R2 * cnt * onetime)
     unsafeAtomicAdd(&film[3 * (size_t)pix + 0], (double)t.x * s);
     unsafeAtomicAdd(&film[3 * (size_t)pix + 1], (double)t.y * s);
@@ -1451,7 +1456,7 @@ struct sppm_ctx {
     bool dep_filter = true;               // deposits no HitPoint can reach are not stored (SPPM_DEP_FILTER=0 keeps them)
     bool has_dual_lobe = false;           // some material reflects and refracts: eye paths branch
     bool one_hp_per_pixel = false;        // no material both stores a HitPoint and sends the eye path on, none branches: a pixel leaves one HitPoint at most
-    DevBuf<PosKey> hp_pos; DevBuf<float4> hp_nr, hp_wgt, hp_tao; DevBuf<HpMeta> hp_meta; DevBuf<double> hp_r2;
+    DevBuf<HpRec> hp_rec; DevBuf<float4> hp_tao; DevBuf<HpMeta> hp_meta; DevBuf<double> hp_r2;
     DevBuf<uint32_t> sorted_of_raw;       // place of every raw HitPoint slot in the sorted arrays (0xffffffff: an unused slot)
     bool meta_valid = false;              // hp_meta holds the HitPoints of the last eye pass (written on demand: ensure_meta)
     uint64_t raw_claimed = 0;             // slots of the raw array the last eye pass claimed
@@ -1630,7 +1635,7 @@ void sppm_destroy(sppm_ctx* ctx) {
     ctx->blob.release(); ctx->texels.release(); ctx->lights.release();
     ctx->raw.release(); ctx->park[0].release(); ctx->park[1].release(); ctx->ntask[0].release(); ctx->ntask[1].release(); ctx->nres.release();
     ctx->hist.release(); ctx->hstart.release();
-    ctx->hp_pos.release(); ctx->hp_nr.release(); ctx->hp_wgt.release(); ctx->hp_tao.release(); ctx->hp_meta.release(); ctx->hp_r2.release(); ctx->sorted_of_raw.release();
+    ctx->hp_rec.release(); ctx->hp_tao.release(); ctx->hp_meta.release(); ctx->hp_r2.release(); ctx->sorted_of_raw.release();
     ctx->dep.release(); ctx->sdep.release(); ctx->pieces.release();
     ctx->place_room.release(); ctx->place_start.release(); ctx->place_over_max.release();
     ctx->dstart.release(); ctx->scan_partial.release(); ctx->ctl.release(); ctx->counters.release(); ctx->pic.release();
@@ -2172,16 +2177,15 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
     // ---- counting sort of the HitPoints by bucket (the histogram is the eye kernel's)
     const uint64_t n = ctx->n_hp;
     tic(ctx, PH_GRID);
-    HIPCHK(ctx->hp_pos.reserve_with_room(n)); HIPCHK(ctx->hp_nr.reserve_with_room(n));
-    HIPCHK(ctx->hp_wgt.reserve_with_room(n)); HIPCHK(ctx->hp_tao.reserve_with_room(n));
+    HIPCHK(ctx->hp_rec.reserve_with_room(n)); HIPCHK(ctx->hp_tao.reserve_with_room(n));
     HIPCHK(ctx->hp_meta.reserve_with_room(n)); HIPCHK(ctx->hp_r2.reserve_with_room(n));
     if (n > 0) {
         const int blocks = (int)((claimed + 255) / 256);
         if (int rc = launch_scan(ctx, ctx->hcount(), ctx->hstart.p, M, nullptr, ctx->raw.p, hit_cap)) return rc;   // + chunk tails -> holes
         HIPCHK(ctx->sorted_of_raw.reserve(std::max<uint64_t>(hit_cap, 1)));   // as many as the raw array holds: the claimed count wanders with the jitter, and growing a buffer waits for the GPU
         hipLaunchKernelGGL(k_hp_scatter, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)claimed, ctx->grid,
-                           ctx->hstart.p, ctx->cursor(), ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_wgt.p, ctx->sorted_of_raw.p);
-        hipLaunchKernelGGL(k_hp_occupancy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->hp_pos.p, (uint32_t)n, ctx->grid, ctx->occ(),
+                           ctx->hstart.p, ctx->cursor(), ctx->hp_rec.p, ctx->sorted_of_raw.p);
+        hipLaunchKernelGGL(k_hp_occupancy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->hp_rec.p, (uint32_t)n, ctx->grid, ctx->occ(),
                            ctx->hp_r2.p, ctx->hp_tao.p);
         HIPCHK(hipGetLastError());
     }
@@ -2267,11 +2271,11 @@ static int launch_gather(sppm_ctx* ctx, const uint32_t* dstart, const uint32_t* 
     const uint32_t piece_cap = 1u << 20;
     HIPCHK(ctx->pieces.reserve(piece_cap));
 #define SPPM_LAUNCH_GATHER(FIXED, SHARE)                                                                                                                        \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<FIXED>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_r2.p,            \
-                       ctx->hp_wgt.p, ctx->hp_tao.p, (uint32_t)ctx->n_hp, dstart, dlen, ctx->sdep.p, ctx->grid, ctx->tile_ctr(), ctx->pieces.p,         \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<FIXED>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_rec.p, ctx->hp_r2.p,                          \
+                       ctx->hp_tao.p, (uint32_t)ctx->n_hp, dstart, dlen, ctx->sdep.p, ctx->grid, ctx->tile_ctr(), ctx->pieces.p,                        \
                        ctx->scalars() + SC_PIECES, piece_cap, ctx->counters.p);                                                                          \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_split<FIXED, SHARE>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_pos.p, ctx->hp_nr.p, ctx->hp_r2.p, \
-                       ctx->hp_wgt.p, ctx->hp_tao.p, (uint32_t)ctx->n_hp, dstart, dlen, ctx->sdep.p, ctx->grid, ctx->pieces.p,                          \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_split<FIXED, SHARE>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_rec.p, ctx->hp_r2.p, \
+                       ctx->hp_tao.p, (uint32_t)ctx->n_hp, dstart, dlen, ctx->sdep.p, ctx->grid, ctx->pieces.p,                                         \
                        ctx->scalars() + SC_PIECES, piece_cap, ctx->scalars() + SC_NEXT_PIECE, ctx->counters.p, over, ctx->scalars() + SC_OVER,           \
                        (unsigned long long)dep_cap, ctx->place_over_max.p, ctx->hstart.p)
     const bool share = shares_gpu(ctx->device);
@@ -2439,10 +2443,10 @@ int sppm_resolve_device(sppm_ctx* ctx, float* dev_pic) {
         const double inv_norm = 1.0 / SPPM_PI / ((double)ctx->last_rounds * (double)ctx->last_per_round);
         const int blocks = (int)((ctx->n_hp + 255) / 256);
         if (ctx->one_hp_per_pixel)
-            hipLaunchKernelGGL(k_resolve<true>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_r2.p, ctx->hp_wgt.p, ctx->hp_tao.p, (uint32_t)ctx->n_hp,
+            hipLaunchKernelGGL(k_resolve<true>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_r2.p, ctx->hp_rec.p, ctx->hp_tao.p, (uint32_t)ctx->n_hp,
                                inv_norm, dev_pic);
         else
-            hipLaunchKernelGGL(k_resolve<false>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_r2.p, ctx->hp_wgt.p, ctx->hp_tao.p, (uint32_t)ctx->n_hp,
+            hipLaunchKernelGGL(k_resolve<false>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->hp_r2.p, ctx->hp_rec.p, ctx->hp_tao.p, (uint32_t)ctx->n_hp,
                                inv_norm, dev_pic);
         HIPCHK(hipGetLastError());
     }
@@ -2481,22 +2485,21 @@ int sppm_get_hitpoints(sppm_ctx* ctx, sppm_hitpoint* out, uint64_t cap, uint64_t
     HIPCHK(hipSetDevice(ctx->device));
     if (int rc = ensure_meta(ctx)) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));   // the copies below go through the null stream, which a caller's stream need not wait for
-    std::vector<PosKey> pos(m); std::vector<float4> nr(m), wg(m), tao(m); std::vector<HpMeta> meta(m); std::vector<double> r2(m);
+    std::vector<HpRec> rec(m); std::vector<float4> tao(m); std::vector<HpMeta> meta(m); std::vector<double> r2(m);
     HIPCHK(hipMemcpy(r2.data(), ctx->hp_r2.p, m * sizeof(double), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(pos.data(), ctx->hp_pos.p, m * sizeof(PosKey), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(nr.data(), ctx->hp_nr.p, m * sizeof(float4), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(wg.data(), ctx->hp_wgt.p, m * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rec.data(), ctx->hp_rec.p, m * sizeof(HpRec), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(tao.data(), ctx->hp_tao.p, m * sizeof(float4), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(meta.data(), ctx->hp_meta.p, m * sizeof(HpMeta), hipMemcpyDeviceToHost));
     for (uint64_t i = 0; i < m; i++) {
         sppm_hitpoint& h = out[i];
-        h.pos[0] = pos[i].x; h.pos[1] = pos[i].y; h.pos[2] = pos[i].z;
-        h.n[0] = nr[i].x; h.n[1] = nr[i].y; h.n[2] = nr[i].z; h.R2 = r2[i];
+        const PosKey& pk = rec[i].a; const float4& nr_i = rec[i].nr; const float4& wg_i = rec[i].wgt;
+        h.pos[0] = pk.x; h.pos[1] = pk.y; h.pos[2] = pk.z;
+        h.n[0] = nr_i.x; h.n[1] = nr_i.y; h.n[2] = nr_i.z; h.R2 = r2[i];
         h.v[0] = meta[i].v[0]; h.v[1] = meta[i].v[1]; h.v[2] = meta[i].v[2];
-        h.wgt[0] = wg[i].x; h.wgt[1] = wg[i].y; h.wgt[2] = wg[i].z;
+        h.wgt[0] = wg_i.x; h.wgt[1] = wg_i.y; h.wgt[2] = wg_i.z;
         h.tao[0] = tao[i].x; h.tao[1] = tao[i].y; h.tao[2] = tao[i].z;
         int pix, newN;
-        memcpy(&pix, &wg[i].w, 4); memcpy(&newN, &tao[i].w, 4);
+        memcpy(&pix, &wg_i.w, 4); memcpy(&newN, &tao[i].w, 4);
         h.x = pix / ctx->cam.w; h.y = pix % ctx->cam.w;
         h.obj = meta[i].obj; h.node = meta[i].node; h.N = meta[i].N; h.newN = newN;
     }
@@ -2544,7 +2547,7 @@ int sppm_get_device_stats(sppm_ctx* ctx, sppm_device_stats* out) {
     add(ctx->sub_box.n, sizeof(float)); add(ctx->lights.n, sizeof(DevLight)); add(ctx->raw.n, sizeof(RawHit));
     for (int k = 0; k < 2; k++) { add(ctx->park[k].n, sizeof(ParkRec)); add(ctx->ntask[k].n, sizeof(NewtonTask)); }
     add(ctx->nres.n, sizeof(float4)); add(ctx->hstart.n, 4); add(ctx->hist.n, 4);
-    add(ctx->hp_pos.n, sizeof(PosKey)); add(ctx->hp_nr.n, sizeof(float4)); add(ctx->hp_wgt.n, sizeof(float4)); add(ctx->hp_tao.n, sizeof(float4));
+    add(ctx->hp_rec.n, sizeof(HpRec)); add(ctx->hp_tao.n, sizeof(float4));
     add(ctx->hp_meta.n, sizeof(HpMeta)); add(ctx->hp_r2.n, sizeof(double));
     add(ctx->dep.n, sizeof(Deposit)); add(ctx->sdep.n, sizeof(Deposit)); add(ctx->pieces.n, sizeof(GatherPiece));
     add(ctx->place_room.n, 4); add(ctx->place_start.n, 4); add(ctx->place_over_max.n, 8); add(ctx->dstart.n, 4); add(ctx->scan_partial.n, 4);
@@ -2927,7 +2930,7 @@ int sppm_film_add(sppm_ctx* ctx, sppm_film* film) {
     tic(ctx, PH_RESOLVE);
     if (ctx->n_hp > 0) {
         const double inv_norm = 1.0 / SPPM_PI / ((double)ctx->last_rounds * (double)ctx->last_per_round);
-        hipLaunchKernelGGL(k_film_add, dim3((unsigned)((ctx->n_hp + 255) / 256)), dim3(256), 0, ctx->stream, ctx->hp_r2.p, ctx->hp_wgt.p,
+        hipLaunchKernelGGL(k_film_add, dim3((unsigned)((ctx->n_hp + 255) / 256)), dim3(256), 0, ctx->stream, ctx->hp_r2.p, ctx->hp_rec.p,
                            ctx->hp_tao.p, (uint32_t)ctx->n_hp, inv_norm, film->acc.p);
         HIPCHK(hipGetLastError());
     }
