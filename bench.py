@@ -94,7 +94,7 @@ PEAK_TLANE_CYCLES = SIMD_CYCLES_PER_S * 64 / 1e12            # ... and in lane-c
 def _kernel(d, name):
     """The summary's entry for a kernel, template arguments or not (k_gather, k_gather<true>)."""
     for k, v in d.items():
-        if k == name or k.startswith(name + "<") or (name.endswith("<1") and k.startswith(name)):
+        if k == name or k.startswith(name + "<") or (name[-2:] in ("<0", "<1") and k.startswith(name)):
             return v
     return {}
 
@@ -334,6 +334,20 @@ def main():
             "valu_wave_instructions_per_launch": gv["valu_wave_instructions"] if gv else None,
             "avg_launch_ms": gather_s * 1e3, "counters_source": src, "measured": how,
         }
+        # ---- the GPU as a whole over the timed region: with several iterations in flight the kernels of different iterations
+        # share the vector units, and no single kernel's figure says how busy those are
+        iter_s = elapsed / args.steps
+        big = [_kernel(pk, "k_trace<1"), _kernel(pk, "k_trace<0"), gc, gs]      # one launch each per iteration
+        if all(k.get("SQ_ACTIVE_INST_VALU") for k in big) and iter_s > 0:
+            act = sum(k["SQ_ACTIVE_INST_VALU"] for k in big)
+            thr = sum(k.get("SQ_THREAD_CYCLES_VALU", 0.0) for k in big)
+            roofline["timed_region_all_kernels"] = {
+                "valu_busy_frac": act * 4.0 / (iter_s * SIMD_CYCLES_PER_S),
+                "lane_frac": thr * 4.0 / (iter_s * SIMD_CYCLES_PER_S * 64.0) if thr else None,
+                "is": "vector-unit cycles (and lane-cycles) of the four large kernels of an iteration (photon trace, eye trace, gather, gather split; "
+                      "committed counters, one launch each) / (wall time of an iteration in the timed region x 256 CU x 4 SIMD [x 64 lanes]): how busy "
+                      "the vector units of the whole GPU are while the kernels of several iterations share them",
+            }
         out = {
             "metric": "Mphotons/s", "value": photons_total / elapsed / 1e6, "unit": "Mphotons/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

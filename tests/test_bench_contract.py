@@ -43,6 +43,8 @@ def test_bench_line_keeps_the_contract():
         assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0 < r["frac"] <= 1
         assert 0 < r["valu_busy_frac"] <= 1 and 0 < r["lanes_active"] <= 64
         assert r["traffic"] is None or r["traffic"] > 0
+        a = r["timed_region_all_kernels"]                 # the whole GPU while several iterations share it
+        assert 0 < a["valu_busy_frac"] <= 1 and 0 < a["lane_frac"] <= a["valu_busy_frac"]
     g = d["roofline_gather"]
     assert g["bound"] == "hbm" and g["unit"] == "GB/s" and g["peak"] == 8000.0 and g["avg_launch_ms"] > 0
     assert g["compulsory_bytes"] > 0 and g["reference_equivalent_bytes"] > g["compulsory_bytes"]
