@@ -31,6 +31,7 @@ enum { P_EMIT = 0, P_NEWTON = 1, P_ROULETTE = 2, P_DIFFUSE = 3 };
 enum { D_EYE = 0, D_PHOTON = 1 };
 enum { OBJ_PLANE = 0, OBJ_SPHERE = 1, OBJ_BEZIER = 2 };
 enum { F_DIFF = 1, F_REFL = 2, F_REFR = 4 };
+enum { A_PLANE_X = 3, A_PLANE_Y = 4, A_PLANE_Z = 5 };     // DevObject::akind beyond the object types
 
 struct DevObject {
     double p0[3];
@@ -49,6 +50,9 @@ struct DevObject {
     int tex_rows, tex_cols;     // the object's texture, copied here so that a lookup starts from LDS (texture < 0: unused)
     unsigned tex_off;           // first texel in the packed uchar4 array
     int lobe;                   // F_DIFF / F_REFL / F_REFR if exactly one of diffr, reflr, refrr is positive (Obj::Roulette then has one outcome), else 0
+    int akind;                  // what the plane / sphere loop runs for this object: its type, or A_PLANE_X + k for a plane whose normal is +-1 along axis k
+    int tex_udex, tex_vdex;     // plane: the coordinates its texture is laid along (Obj.h:86-100)
+    int pad0;
     double inv_radius;          // sphere: 1 / radius
     double inv_refrn;           // 1 / refrn (Raytracer.h:187, :332)
 };
@@ -66,6 +70,7 @@ struct DevLight {
 };
 
 // Scene tables staged in LDS by every workgroup: objects | patch AABBs | control points.
+struct AObj;
 struct SceneView {
     const DevObject* objs;      // LDS
     const double* patch_box;    // LDS, n_patches x 6 (pmin, pmax)
@@ -75,12 +80,21 @@ struct SceneView {
     const float* pw_q;
     const double* pw_c;
     const int* patch_obj;       // LDS, n_patches: owning object of each patch
+    const struct AObj* aobj;    // LDS, n_objs: what the plane / sphere tests read of each object (analytic_nearest)
     // Per patch the boxes of its 4 x 4 sub-patches (global memory, n_patches x 16 x {lo xyz, hi xyz}, fp32 rounded
     // outwards), each grown by SPPM_SUBBOX_MARGIN; null: no such table (see subbox_prune)
     const float* sub_box;
     int n_objs;
     int n_patches;
     const uchar4* texels;       // global
+    // The Bezier objects by index, one byte each, so that the loops over them do not read the type of every object from LDS
+    // in every turn of the trace loop; n_bez < 0: not listed (more than eight, or an index beyond 255), the loops scan the objects
+    int n_bez;
+    uint64_t bez_idx;
+    // The objects in index order as runs of one DevObject::akind, a byte each (kind | length << 4, length <= 15), for the
+    // plane / sphere loop; n_runs < 0: more than sixteen runs, the loop reads every object's kind from its record
+    int n_runs;
+    uint64_t runs_lo, runs_hi;
 };
 
 // ------------------------------------------------------------------ RNG
@@ -669,6 +683,19 @@ __device__ __forceinline__ void near_consider(Near& n, double dist, int obj, int
 }
 
 // Planes and spheres (Obj.h:65-85, :111-139), per lane, fp64.
+//
+// Shaped for a wave that is alone (or nearly) on its SIMD, which is how the trace kernels run: such a wave pays about 24
+// cycles for a taken branch, 12 for one not taken, as much again for every compare -> exec-mask hand-over and 60 and more
+// for an LDS round trip, against 4 to 5 for a vector instruction.  So (1) the bodies are straight-line code whose guards
+// (Obj.h:68-76, :117-128) are conjoined into ONE select: what a guard protects against cannot reach the record, since a
+// quotient by a projection that IsZero comes out finite, infinite or NaN and is deselected by its own guard bit, and the
+// square root is taken of max(det2, tiny) and deselected where det2 < EPS; (2) the objects are walked in index order
+// (the order decides ties, Scene.h:171-178) as RUNS of one kind: the kind and length of each run come packed in scalar
+// registers (a kernel argument), the dispatch happens once per run with no lane value behind it, and a run is a tight loop
+// around one body; (3) the loop reads a table of 32-byte records (AObj) that holds just what the tests read, the next
+// object's record asked for before the current one is worked on.
+struct __attribute__((aligned(16))) AObj { double a, b, c, r; };   // axis plane k: a = P0[k]; sphere: centre (a, b, c), radius r; else unused
+#define SPPM_MAX_RUNS 16
 __device__ __forceinline__ void analytic_nearest(const SceneView& S, bool active, d3 o, d3 d, Near& nr) {
 #ifdef ABLATE_ANALYTIC
     if (active) near_consider(nr, 10.0 + d.x, d.y > 0 ? 3 : 0, 0, -1, 0, 0, 0);
@@ -679,43 +706,89 @@ __device__ __forceinline__ void analytic_nearest(const SceneView& S, bool active
     // near_init left them, so three values are carried through the loop instead of eight.
     double best = nr.dist;
     int bobj = nr.obj, binside = nr.inside;
-    // The object records sit in LDS; the next object's fields are asked for before the current one is worked on,
-    // so that with two or three waves per SIMD the LDS latency is not paid once per object.
-    const int n_objs = S.n_objs;
-    d3 q_p0 = mk(0, 0, 0), q_n = mk(0, 0, 0);
-    double q_r = 0;
-    int q_type = -1;
-    if (n_objs > 0) { q_p0 = ld3(S.objs[0].p0); q_n = ld3(S.objs[0].n); q_r = S.objs[0].radius; q_type = S.objs[0].type; }
-    for (int a = 0; a < n_objs; a++) {
-        const d3 p0 = q_p0, n = q_n;
-        const double radius = q_r;
-        const int type = __builtin_amdgcn_readfirstlane(q_type);   // wave-uniform: keep the branch scalar
-        if (a + 1 < n_objs) {
-            const DevObject& nx = S.objs[a + 1];
-            q_p0 = ld3(nx.p0); q_n = ld3(nx.n); q_r = nx.radius; q_type = nx.type;
-        }
-        if (type == OBJ_PLANE) {
-            double project = dot(d, n);
-            if (active && !is_zero(project)) {
 #if SPPM_FAST_DIV
-                double dist = dot(p0 - o, n) * rcp_nr(project);      // the quotient to the last place or two, in half the instructions
-#else
-                double dist = dot(p0 - o, n) / project;
+    const double ix = rcp_nr(d.x), iy = rcp_nr(d.y), iz = rcp_nr(d.z);   // for the axis planes; a zero component gives inf / NaN, deselected below
 #endif
-                if (dist > SPPM_EPS && dist < best) { best = dist; bobj = a; binside = 0; }
+    const bool ax_ok = active & !is_zero(d.x), ay_ok = active & !is_zero(d.y), az_ok = active & !is_zero(d.z);
+    // Two objects that are the same object listed twice must get the same bits wherever they are worked on (the first
+    // listed wins a tie): no contraction is left to the compiler in these bodies, every fused operation is written out.
+    auto dotf = [](const d3 u, const d3 v) { return fma(u.z, v.z, fma(u.y, v.y, u.x * v.x)); };
+    // A plane whose normal is +-1 along one axis k (every wall of the reference's scene): the two dot products of
+    // Obj.h:65-84 have one non-zero term each, dot(d, n) = d[k] n[k] and dot(P0 - o, n) = (P0[k] - o[k]) n[k], both
+    // exact, and the sign n[k] cancels in the quotient (rcp_nr is odd): the same bits as the general form gives.
+    auto axis_plane = [&](const int a, const double pk, const double ok_, const double dk, const double ik, const bool dir_ok) {
+#pragma clang fp contract(off)
+#if SPPM_FAST_DIV
+        const double dist = (pk - ok_) * ik;
+#else
+        const double dist = (pk - ok_) / dk;
+#endif
+        const bool ok = dir_ok & (dist > SPPM_EPS) & (dist < best);
+        best = ok ? dist : best; bobj = ok ? a : bobj; binside = ok ? 0 : binside;
+    };
+    auto sphere = [&](const int a, const AObj& q) {
+#pragma clang fp contract(off)
+        const d3 L = mk(q.a, q.b, q.c) - o;
+        const double project = dotf(L, d);
+        const double det2 = fma(q.r, q.r, -fma(-project, project, dotf(L, L)));    // r^2 - (|L|^2 - project^2)
+        const double pos = fmax(det2, 1e-300);
+        const double det = pos * rsqrt_nr(pos);                                    // sqrt_nr without its branch
+        const double dist1 = project - det, dist2 = project + det;
+        const double dist = (dist1 > SPPM_EPS) ? dist1 : dist2;
+        const bool ok = active & !(det2 < SPPM_EPS) & !(dist2 < SPPM_EPS) & (dist < best);
+        best = ok ? dist : best; bobj = ok ? a : bobj; binside = ok ? ((dist1 < SPPM_EPS) ? 1 : 0) : binside;
+    };
+    auto plane = [&](const int a) {   // a plane in general position: read where it lies, none of the reference's scene is one
+#pragma clang fp contract(off)
+        const d3 p0 = ld3(S.objs[a].p0), n = ld3(S.objs[a].n);
+        const double project = dotf(d, n);
+#if SPPM_FAST_DIV
+        const double dist = dotf(p0 - o, n) * rcp_nr(project);      // the quotient to the last place or two, in half the instructions
+#else
+        const double dist = dotf(p0 - o, n) / project;
+#endif
+        const bool ok = active & !is_zero(project) & (dist > SPPM_EPS) & (dist < best);
+        best = ok ? dist : best; bobj = ok ? a : bobj; binside = ok ? 0 : binside;
+    };
+#if !SPPM_FAST_DIV
+    const double ix = 0, iy = 0, iz = 0;
+#endif
+    const int n_runs = S.n_runs;
+    if (n_runs >= 0) {
+        AObj q = S.aobj[0];                      // the table ends with a spare record: the look-ahead never leaves it
+        int a = 0;
+        for (int r = 0; r < n_runs; r++) {
+            const uint32_t code = (uint32_t)((r < 8 ? S.runs_lo >> (8 * r) : S.runs_hi >> (8 * (r - 8))) & 0xffu);
+            const int kind = (int)(code & 15u), end = a + (int)(code >> 4);
+            if (kind == A_PLANE_X) {
+#pragma unroll 1
+                for (; a < end; a++) { const double pk = q.a; q = S.aobj[a + 1]; axis_plane(a, pk, o.x, d.x, ix, ax_ok); }
+            } else if (kind == A_PLANE_Y) {
+#pragma unroll 1
+                for (; a < end; a++) { const double pk = q.a; q = S.aobj[a + 1]; axis_plane(a, pk, o.y, d.y, iy, ay_ok); }
+            } else if (kind == A_PLANE_Z) {
+#pragma unroll 1
+                for (; a < end; a++) { const double pk = q.a; q = S.aobj[a + 1]; axis_plane(a, pk, o.z, d.z, iz, az_ok); }
+            } else if (kind == OBJ_SPHERE) {
+#pragma unroll 1
+                for (; a < end; a++) { const AObj c = q; q = S.aobj[a + 1]; sphere(a, c); }
+            } else {
+                if (kind == OBJ_PLANE)
+                    for (; a < end; a++) plane(a);
+                a = end;
+                q = S.aobj[a];
             }
-        } else if (type == OBJ_SPHERE) {
-            d3 L = p0 - o;
-            double project = dot(L, d);
-            double det2 = radius * radius - (dot(L, L) - project * project);
-            if (active && !(det2 < SPPM_EPS)) {
-                double det = sqrt_nr(det2);
-                double dist1 = project - det, dist2 = project + det;
-                if (!(dist2 < SPPM_EPS)) {
-                    const double dist = (dist1 > SPPM_EPS) ? dist1 : dist2;
-                    if (dist < best) { best = dist; bobj = a; binside = (dist1 < SPPM_EPS) ? 1 : 0; }
-                }
-            }
+        }
+    } else {   // more runs than the packed form holds: one object at a time, its kind from its record
+        const int n_objs = S.n_objs;
+        for (int a = 0; a < n_objs; a++) {
+            const int kind = __builtin_amdgcn_readfirstlane(S.objs[a].akind);
+            const AObj q = S.aobj[a];
+            if (kind == A_PLANE_X) axis_plane(a, q.a, o.x, d.x, ix, ax_ok);
+            else if (kind == A_PLANE_Y) axis_plane(a, q.a, o.y, d.y, iy, ay_ok);
+            else if (kind == A_PLANE_Z) axis_plane(a, q.a, o.z, d.z, iz, az_ok);
+            else if (kind == OBJ_SPHERE) sphere(a, q);
+            else if (kind == OBJ_PLANE) plane(a);
         }
     }
     if (bobj != nr.obj || best != nr.dist) { nr.dist = best; nr.obj = bobj; nr.inside = binside; nr.patch = -1; nr.t = 0; nr.u = 0; nr.v = 0; }
@@ -726,10 +799,17 @@ __device__ __forceinline__ void bezier_nearest_coop(const SceneView& S, bool act
 #ifdef ABLATE_BEZIER
     return;
 #endif
-    for (int a = 0; a < S.n_objs; a++) {
+    const int n_loop = S.n_bez >= 0 ? S.n_bez : S.n_objs;
+    for (int k = 0; k < n_loop; k++) {
+        const int a = S.n_bez >= 0 ? (int)((S.bez_idx >> (8 * k)) & 0xffu) : k;
         const DevObject& ob = S.objs[a];
-        if (__builtin_amdgcn_readfirstlane(ob.type) != OBJ_BEZIER) continue;
-        bool need = active && aabb_hit(ob.bmin, o, d);
+        if (S.n_bez < 0 && __builtin_amdgcn_readfirstlane(ob.type) != OBJ_BEZIER) continue;
+        // The object's box (Bezier.h:244) is tested by every lane in every turn of the trace loop, and three rays in a
+        // thousand enter it: the fp32 may-hit test answers first (a "no" is certain), and the reference's fp64 test with its
+        // three divisions runs only in a wave where some lane says maybe.  bmin and bmax lie side by side: one box of six.
+        float obj_lb;
+        bool need = active && aabb_may_hit_lb(ob.bmin, o, d, obj_lb);
+        if (__ballot(need)) need = need && aabb_hit(ob.bmin, o, d);
         float t, u, v;
         int patch;
         bezier_coop(S, ob, need, o, d, path_hash, vertex, (float)nr.dist, t, u, v, patch, newton_calls);
@@ -745,11 +825,15 @@ __device__ __forceinline__ void bezier_patch_masks(const SceneView& S, bool acti
     const int lane = lane_id();
 #pragma unroll
     for (int w = 0; w < SPPM_MASK_WORDS; w++) words[w] = 0;
-    for (int a = 0; a < S.n_objs; a++) {
+    const int n_loop = S.n_bez >= 0 ? S.n_bez : S.n_objs;
+    for (int k = 0; k < n_loop; k++) {
+        const int a = S.n_bez >= 0 ? (int)((S.bez_idx >> (8 * k)) & 0xffu) : k;
         const DevObject& ob = S.objs[a];
-        if (__builtin_amdgcn_readfirstlane(ob.type) != OBJ_BEZIER) continue;
+        if (S.n_bez < 0 && __builtin_amdgcn_readfirstlane(ob.type) != OBJ_BEZIER) continue;
         const int n_patches = __builtin_amdgcn_readfirstlane(ob.n_patches), first_patch = __builtin_amdgcn_readfirstlane(ob.first_patch);
-        bool need = active && aabb_hit(ob.bmin, o, d);
+        float obj_lb;
+        bool need = active && aabb_may_hit_lb(ob.bmin, o, d, obj_lb);                  // as in bezier_nearest_coop
+        if (__ballot(need)) need = need && aabb_hit(ob.bmin, o, d);
         uint64_t m = __ballot(need);
         while (m) {
             int src = __ffsll((unsigned long long)m) - 1;
@@ -809,10 +893,8 @@ __device__ __forceinline__ Hit finish_hit(const SceneView& S, d3 o, d3 d, const 
         if (ob.type == OBJ_PLANE) {
             h.n = ld3(ob.n);
             if (ob.texture >= 0) {                                                        // Obj.h:86-100
-                d3 nn = ld3(ob.n), p0 = ld3(ob.p0);
-                int ndir = 0;
-                for (int i = 0; i < 3; i++) if (comp(nn, i) != 0) ndir = i;
-                int vdex = (ndir + 2) % 3, udex = (ndir + 1) % 3;
+                const d3 p0 = ld3(ob.p0);
+                const int vdex = ob.tex_vdex, udex = ob.tex_udex;   // (ndir + 2) % 3, (ndir + 1) % 3, ndir = the last non-zero component of the normal
 #if SPPM_FAST_DIV
                 double v = 0.5 + (comp(h.pos, vdex) - comp(p0, vdex)) * (1.0 / 400.0);      // Module(Vec3(400, 0, 0)), Obj.h:95
                 double u = 0.5 + (comp(h.pos, udex) - comp(p0, udex)) * (1.0 / 300.0);

@@ -60,11 +60,15 @@ struct NewtonTask { uint32_t park, patch; };
 
 struct SceneParams {
     const char* blob;
-    int blob_bytes, off_box, off_cp, off_pobj, off_sub, n_objs, n_patches;   // off_sub < 0: the sub-patch boxes are not in the blob
+    int blob_bytes, off_box, off_cp, off_pobj, off_sub, off_aobj, n_objs, n_patches;   // off_sub < 0: the sub-patch boxes are not in the blob
     const uchar4* texels;
     const float* pw_q;      // Newton tables: power-basis coefficients around the patch centre, n_patches x 48
     const double* pw_c;     // and the centres, n_patches x 3
     const float* sub_box;   // boxes of the 4 x 4 sub-patches of every patch (SceneView::sub_box) where the blob has no room for them, or null
+    int n_bez;              // SceneView::n_bez, bez_idx
+    unsigned long long bez_idx;
+    int n_runs;             // SceneView::n_runs, runs_lo, runs_hi
+    unsigned long long runs_lo, runs_hi;
 };
 
 struct DevCounters {
@@ -124,9 +128,15 @@ __device__ __forceinline__ SceneView stage_scene(const SceneParams& sp) {
     S.pw_c = sp.pw_c;
     S.sub_box = sp.off_sub >= 0 ? (const float*)(base + sp.off_sub) : sp.sub_box;
     S.patch_obj = (const int*)(base + sp.off_pobj);
+    S.aobj = (const AObj*)(base + sp.off_aobj);
     S.n_objs = sp.n_objs;
     S.n_patches = sp.n_patches;
     S.texels = sp.texels;
+    S.n_bez = sp.n_bez;
+    S.bez_idx = sp.bez_idx;
+    S.n_runs = sp.n_runs;
+    S.runs_lo = sp.runs_lo;
+    S.runs_hi = sp.runs_hi;
     return S;
 }
 
@@ -215,6 +225,7 @@ enum { MODE_EYE = 0, MODE_PHOTON = 1 };
 #ifndef TRACE_SLOT_CHUNK
 #define TRACE_SLOT_CHUNK 256u
 #endif
+#define TRACE_LDS_LIGHTS 16        // lights kept in LDS by the photon kernel (40 bytes each); more are read from global memory
 #define DEP_HOLE 0x00ffffffu      // DepB::bucket of a claimed but unused slot (buckets are < 2^22)
 
 struct TraceParams {
@@ -289,6 +300,18 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
     unsigned long long chunk_base = 0;                  // first item of the chunk the emission directions in LDS belong to
     // per-wave LDS slice behind the scene tables: emission directions of the claimed photon chunk
     double* emit_dir = (double*)((char*)lds_scene + (IN_LDS ? ((sp.blob_bytes + 15) & ~15) : 0)) + (threadIdx.x >> 6) * (3 * 128);
+    // Up to TRACE_LDS_LIGHTS lights are copied behind the emission slices: a refill then reads its light from LDS instead of
+    // waiting for a vector load from global memory at the head of a turn of the loop.
+    DevLight* lds_lights = (DevLight*)((double*)((char*)lds_scene + (IN_LDS ? ((sp.blob_bytes + 15) & ~15) : 0)) + 4 * (3 * 128));
+    const bool lights_in_lds = MODE == MODE_PHOTON && tp.n_lights <= TRACE_LDS_LIGHTS;
+    if (MODE == MODE_PHOTON) {
+        if (lights_in_lds) {
+            const uint32_t* src = (const uint32_t*)tp.lights;
+            uint32_t* dst = (uint32_t*)lds_lights;
+            for (uint32_t i = threadIdx.x; i < (uint32_t)tp.n_lights * (uint32_t)(sizeof(DevLight) / 4); i += blockDim.x) dst[i] = src[i];
+        }
+        __syncthreads();
+    }
     unsigned long long slot_next = 0, slot_end = 0;     // this wave's open chunk of output slots (deposits / raw HitPoints), wave-uniform
     const uint32_t wave_slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     slot_next = tp.wave_chunks[2 * wave_slot];
@@ -300,6 +323,9 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
 #endif
     for (;;) {
         STAMP(7);
+#ifdef TRACE_STAMP_ITERS
+        st_sum[3] -= 1000000000ull;   // diagnostic: the loop's turns, counted in the merge / park slot (a billion off per turn)
+#endif
         // ---- refill idle lanes
         const uint64_t idle = __ballot(!active);
         if (idle && work_next >= work_end && !exhausted) {
@@ -378,11 +404,16 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
                         carry[0] = carry[1] = carry[2] = 1.0f;
                     } else {
                         // Raytracer.h:220-233: round by round, light by light; one light (the reference's scene) needs no division
-                        const DevLight& L = tp.lights[tp.n_lights == 1 ? 0u : (uint32_t)(((uint32_t)g / tp.per_round) % (uint32_t)tp.n_lights)];
+                        const uint32_t li = tp.n_lights == 1 ? 0u : (uint32_t)(((uint32_t)g / tp.per_round) % (uint32_t)tp.n_lights);
                         const uint32_t e = (uint32_t)(my - chunk_base);                   // the direction drawn when the chunk was claimed
                         d = mk(emit_dir[3 * e + 0], emit_dir[3 * e + 1], emit_dir[3 * e + 2]);
-                        o = ld3(L.pos);                                                   // Light::emit, Light.h:8-13
-                        carry[0] = L.flux[0]; carry[1] = L.flux[1]; carry[2] = L.flux[2];
+                        if (lights_in_lds) {                                              // Light::emit, Light.h:8-13
+                            const DevLight& L = lds_lights[li];
+                            o = ld3(L.pos); carry[0] = L.flux[0]; carry[1] = L.flux[1]; carry[2] = L.flux[2];
+                        } else {
+                            const DevLight& L = tp.lights[li];
+                            o = ld3(L.pos); carry[0] = L.flux[0]; carry[1] = L.flux[1]; carry[2] = L.flux[2];
+                        }
                         took_photon = true;
                     }
                 }
@@ -1411,7 +1442,7 @@ struct sppm_ctx {
     std::string err;
     // scene
     bool have_scene = false;
-    DevBuf<char> blob; int blob_bytes = 0, off_box = 0, off_cp = 0, off_pobj = 0, off_sub = -1, n_objs = 0, n_patches = 0;
+    DevBuf<char> blob; int blob_bytes = 0, off_box = 0, off_cp = 0, off_pobj = 0, off_aobj = 0, off_sub = -1, n_objs = 0, n_patches = 0;
     bool scene_in_lds = true;             // the scene tables fit the LDS staging area (else: read from global memory)
     bool coop_only = false;               // more patches than a parked ray's patch mask can name: rays are never parked
     DevBuf<uchar4> texels;
@@ -1504,14 +1535,20 @@ struct sppm_ctx {
     std::vector<Span> spans;
     int gather_launches = 0, trace_launches = 0;
     int num_cu = 256;
+    int n_bez = -1;                       // SceneView::n_bez, bez_idx
+    unsigned long long bez_idx = 0;
+    int n_runs = -1;                      // SceneView::n_runs, runs_lo, runs_hi
+    unsigned long long runs_lo = 0, runs_hi = 0;
 
     SceneParams scene_params() const {
         SceneParams sp;
-        sp.blob = blob.p; sp.blob_bytes = blob_bytes; sp.off_box = off_box; sp.off_cp = off_cp; sp.off_pobj = off_pobj;
+        sp.blob = blob.p; sp.blob_bytes = blob_bytes; sp.off_box = off_box; sp.off_cp = off_cp; sp.off_pobj = off_pobj; sp.off_aobj = off_aobj;
         sp.n_objs = n_objs; sp.n_patches = n_patches; sp.texels = texels.p;
         sp.pw_q = pw_q.p; sp.pw_c = pw_c.p;
         sp.off_sub = off_sub;
         sp.sub_box = (use_sub_box && n_patches > 0 && off_sub < 0) ? sub_box.p : nullptr;
+        sp.n_bez = n_bez; sp.bez_idx = bez_idx;
+        sp.n_runs = n_runs; sp.runs_lo = runs_lo; sp.runs_hi = runs_hi;
         return sp;
     }
 };
@@ -1706,7 +1743,8 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
     const int off_box = (int)(((size_t)no * sizeof(DevObject) + 15) & ~(size_t)15);
     const int off_cp = off_box + np * 6 * (int)sizeof(double);
     const int off_pobj = off_cp + np * 48 * (int)sizeof(float);
-    int bytes = (off_pobj + np * (int)sizeof(int) + 15) & ~15;
+    const int off_aobj = (off_pobj + np * (int)sizeof(int) + 15) & ~15;
+    int bytes = (off_aobj + (no + 1) * (int)sizeof(AObj) + 15) & ~15;   // one spare record: the plane / sphere loop looks one ahead
     // the sub-patch boxes ride in the blob (and so in LDS) where that keeps it within the staging area
     int off_sub = -1;
     if (!sb.empty() && (size_t)bytes + sb.size() * sizeof(float) <= SCENE_LDS_MAX) { off_sub = bytes; bytes += (int)(sb.size() * sizeof(float)); }
@@ -1771,6 +1809,15 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
         o.flags = (any_zero3(so.material.diff) ? 0 : F_DIFF) | (any_zero3(so.material.refl) ? 0 : F_REFL) |
                   (any_zero3(so.material.refr) ? 0 : F_REFR);
         o.first_patch = so.first_patch; o.n_patches = so.n_patches;
+        o.akind = o.type; o.pad0 = 0;
+        if (o.type == OBJ_PLANE)   // normal exactly +-1 along one axis: the one-term form of the plane test
+            for (int k = 0; k < 3; k++)
+                if (std::fabs(o.n[k]) == 1.0 && o.n[(k + 1) % 3] == 0.0 && o.n[(k + 2) % 3] == 0.0) o.akind = A_PLANE_X + k;
+        {   // PlaneObj::GetColor, Obj.h:86-100
+            int ndir = 0;
+            for (int k = 0; k < 3; k++) if (o.n[k] != 0) ndir = k;
+            o.tex_vdex = (ndir + 2) % 3; o.tex_udex = (ndir + 1) % 3;
+        }
         o.tex_rows = o.tex_cols = 0; o.tex_off = 0;
         if (o.texture >= 0) { o.tex_rows = td[o.texture].rows; o.tex_cols = td[o.texture].cols; o.tex_off = td[o.texture].offset; }
         if ((o.flags & F_REFL) && (o.flags & F_REFR)) dual_lobe = true;
@@ -1786,6 +1833,14 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
                     o.bmax[k] = std::max(o.bmax[k], box[6 * p + 3 + k]);
                 }
             }
+        }
+    }
+    {
+        AObj* ao = (AObj*)(blob.data() + off_aobj);     // what the plane / sphere tests read (analytic_nearest)
+        for (int i = 0; i < no; i++) {
+            ao[i].a = ao[i].b = ao[i].c = ao[i].r = 0;
+            if (objs[i].akind >= A_PLANE_X) ao[i].a = objs[i].p0[objs[i].akind - A_PLANE_X];
+            else if (objs[i].type == OBJ_SPHERE) { ao[i].a = objs[i].p0[0]; ao[i].b = objs[i].p0[1]; ao[i].c = objs[i].p0[2]; ao[i].r = objs[i].radius; }
         }
     }
     // Newton tables: Bernstein -> power basis around the patch centre, in fp64 (patch_eval_pw)
@@ -1814,7 +1869,28 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
     }
     HIPCHK(ctx->blob.reserve((size_t)bytes));
     HIPCHK(hipMemcpy(ctx->blob.p, blob.data(), (size_t)bytes, hipMemcpyHostToDevice));
-    ctx->blob_bytes = bytes; ctx->off_box = off_box; ctx->off_cp = off_cp; ctx->off_pobj = off_pobj; ctx->off_sub = off_sub; ctx->n_objs = no; ctx->n_patches = np;
+    {   // the Bezier objects by index, for the loops over them (SceneView::bez_idx)
+        int nb = 0;
+        unsigned long long packed = 0;
+        for (int i = 0; i < no && nb >= 0; i++)
+            if (objs[i].type == OBJ_BEZIER) {
+                if (nb == 8 || i > 255) { nb = -1; break; }
+                packed |= (unsigned long long)i << (8 * nb++);
+            }
+        ctx->n_bez = nb; ctx->bez_idx = nb >= 0 ? packed : 0ull;
+        // the objects in index order as runs of one kind (SceneView::n_runs)
+        int nr = 0;
+        unsigned long long rl[2] = {0, 0};
+        for (int i = 0; i < no && nr >= 0;) {
+            int len = 1;
+            while (i + len < no && len < 15 && objs[i + len].akind == objs[i].akind) len++;
+            if (nr == SPPM_MAX_RUNS) { nr = -1; break; }
+            rl[nr >> 3] |= (unsigned long long)((objs[i].akind & 15) | (len << 4)) << (8 * (nr & 7));
+            nr++; i += len;
+        }
+        ctx->n_runs = nr; ctx->runs_lo = nr >= 0 ? rl[0] : 0ull; ctx->runs_hi = nr >= 0 ? rl[1] : 0ull;
+    }
+    ctx->blob_bytes = bytes; ctx->off_box = off_box; ctx->off_cp = off_cp; ctx->off_pobj = off_pobj; ctx->off_aobj = off_aobj; ctx->off_sub = off_sub; ctx->n_objs = no; ctx->n_patches = np;
     // Large scenes: tables beyond the LDS staging area are read from global memory, and with more patches than the patch
     // mask of a parked ray holds every Bezier solve happens in the tracing wave (the default anyway).
     ctx->scene_in_lds = bytes <= SCENE_LDS_MAX;
@@ -1919,8 +1995,8 @@ static int close_chunks(sppm_ctx* ctx, Deposit* dep, RawHit* hits, uint64_t cap)
 
 template <int MODE>
 static void launch_trace(sppm_ctx* ctx, bool coop, int blocks, const SceneParams& sp, const TraceParams& tp) {
-    // dynamic LDS: the scene tables, then (photon pass) 4 waves x 128 emission directions
-    const size_t lds = (ctx->scene_in_lds ? (((size_t)ctx->blob_bytes + 15) & ~(size_t)15) : 0) + (MODE == MODE_PHOTON ? 4 * 128 * 3 * sizeof(double) : 0);
+    // dynamic LDS: the scene tables, then (photon pass) 4 waves x 128 emission directions and the first lights
+    const size_t lds = (ctx->scene_in_lds ? (((size_t)ctx->blob_bytes + 15) & ~(size_t)15) : 0) + (MODE == MODE_PHOTON ? 4 * 128 * 3 * sizeof(double) + TRACE_LDS_LIGHTS * sizeof(DevLight) : 0);
     if (!ctx->scene_in_lds) hipLaunchKernelGGL((k_trace<MODE, true, false>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);   // coop_only
     else if (coop) hipLaunchKernelGGL((k_trace<MODE, true, true>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
     else hipLaunchKernelGGL((k_trace<MODE, false, true>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
