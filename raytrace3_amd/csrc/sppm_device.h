@@ -70,6 +70,8 @@ struct DevLight {
 };
 
 // Scene tables staged in LDS by every workgroup: objects | patch AABBs | control points.
+// a pointer into LDS, typed as one: a pointer that may be LDS or global memory costs flat loads
+#define SPPM_LDS(T) const __attribute__((address_space(3))) T
 struct AObj;
 struct SceneView {
     const DevObject* objs;      // LDS

@@ -408,8 +408,8 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
                         const uint32_t e = (uint32_t)(my - chunk_base);                   // the direction drawn when the chunk was claimed
                         d = mk(emit_dir[3 * e + 0], emit_dir[3 * e + 1], emit_dir[3 * e + 2]);
                         if (lights_in_lds) {                                              // Light::emit, Light.h:8-13
-                            const DevLight& L = lds_lights[li];
-                            o = ld3(L.pos); carry[0] = L.flux[0]; carry[1] = L.flux[1]; carry[2] = L.flux[2];
+                            SPPM_LDS(DevLight)* L = (SPPM_LDS(DevLight)*)lds_lights + li;   // typed as LDS: no flat load
+                            o = mk(L->pos[0], L->pos[1], L->pos[2]); carry[0] = L->flux[0]; carry[1] = L->flux[1]; carry[2] = L->flux[2];
                         } else {
                             const DevLight& L = tp.lights[li];
                             o = ld3(L.pos); carry[0] = L.flux[0]; carry[1] = L.flux[1]; carry[2] = L.flux[2];
