@@ -1,11 +1,13 @@
 /*
  * sppm_oracle.cpp — CPU oracle of the SPPM hot path.
  *
- * TEST INFRASTRUCTURE ONLY (see sppm_oracle.h).  PARITY UNPINNED: the reference
+ * TEST INFRASTRUCTURE ONLY (see sppm_oracle.h).  PARITY UNPINNED IN VALUE: the reference
  * has no tests or golden vectors and cannot be built here; this file restates
  * its algorithm function by function, in the reference's own operation order
  * and in double (optionally float inside Bezier3::newton), and is pinned by the
- * analytic known-answer tests under tests/.
+ * analytic known-answer tests under tests/ and, in structure only (correlation),
+ * by the one rendered picture the reference's checkout holds
+ * (tests/test_reference_picture.py).
  *
  * Each function cites the reference code it follows (paths relative to the
  * reference checkout, raytracer/...).

@@ -6,9 +6,11 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the
  * product library (libsppm_hip.so) never does.
  *
- * PARITY UNPINNED: the reference ships no tests, golden vectors or runnable
+ * PARITY UNPINNED IN VALUE: the reference ships no tests, golden vectors or runnable
  * build (it needs OpenCV, FLANN, Eigen and MSVC), so this restatement is pinned
- * only by analytic known-answer tests and by reading the source.
+ * by analytic known-answer tests, by reading the source and, in structure only, by
+ * the correlation of its picture of the stock scene with the one picture the
+ * reference's checkout holds (a lossy JPEG of another state of the program).
  */
 #ifndef SPPM_ORACLE_H
 #define SPPM_ORACLE_H
