@@ -410,6 +410,51 @@ def test_two_lights_share_the_per_light_normaliser(gpu):
     _image_parity(gpu.resolve(), o.resolve(), frac=0.995)
 
 
+def test_more_runs_and_lights_than_the_packed_forms_hold(gpu):
+    """The trace kernels take the objects' kinds as runs packed in two kernel arguments (sixteen runs) and the first sixteen
+    lights from LDS; a scene beyond both limits goes through the general routes: 24 objects whose kinds alternate (planes
+    along the three axes, tilted planes, spheres: 24 runs) and 20 lights.  NearCollide equals the oracle's ray for ray, a
+    whole iteration agrees in every HitPoint, tally and to the image tolerance."""
+    rng = np.random.default_rng(77)
+    s = scenes.FlatScene()
+    mats = (scenes.WHITE_DIFF, scenes.MIRROR, scenes.REFR0, scenes.WHITE_DIFF)
+    s.add_plane((50, 0, 81.6), (0, -1, 0), (.75, .75, .75), scenes.WHITE_DIFF)                     # a floor to catch photons
+    for k in range(23):
+        kind = k % 5
+        if kind < 3:                                                                             # a far wall along axis `kind`
+            n = np.zeros(3); n[kind] = rng.choice([-1.0, 1.0])
+            p0 = np.array([50.0, 40.0, 80.0]); p0[kind] += rng.choice([-1.0, 1.0]) * rng.uniform(150, 400)
+            s.add_plane(tuple(p0), tuple(n), tuple(rng.random(3)), mats[k % 4])
+        elif kind == 3:                                                                          # a tilted plane, far away
+            n = rng.normal(size=3)
+            s.add_plane(tuple(np.array([50.0, 40.0, 80.0]) + rng.normal(size=3) * 300), tuple(n), tuple(rng.random(3)), scenes.WHITE_DIFF)
+        else:
+            s.add_sphere(float(rng.uniform(4, 14)), (float(rng.uniform(10, 90)), float(rng.uniform(5, 30)), float(rng.uniform(30, 130))),
+                         tuple(rng.random(3)), mats[k % 4])
+    for k in range(20):
+        s.add_light((float(rng.uniform(20, 80)), float(rng.uniform(40, 70)), float(rng.uniform(40, 120))), tuple(rng.uniform(100, 400, size=3)))
+    assert len(s.objects) == 24 and len(s.light_list) == 20
+    cam = scenes.default_camera(96, 72)
+    o = _run_pair(gpu, s, cam, 20, 100, 0)
+    cg, co = gpu.counters(), o.counters()
+    assert cg["photons"] == co["photons"] == 20 * 100 * 20
+    for k in ("segments", "deposits", "eye_segments"):
+        assert cg[k] == co[k], k
+    for k in ("candidates", "accepted"):
+        assert cg[k] == pytest.approx(co[k], rel=1e-3), k
+    g, c = gpu.hitpoints(), o.hitpoints()
+    assert np.array_equal(np.sort(_key(g)), np.sort(_key(c)))
+    _image_parity(gpu.resolve(), o.resolve(), frac=0.995)
+    n_rays = 4096
+    org = rng.normal(size=(n_rays, 3)) * 30 + [50, 30, 80]
+    d = rng.normal(size=(n_rays, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    hg, hc = gpu.near_collide(org, d, SEED), o.near_collide(org, d, SEED)
+    assert np.array_equal(hg["obj"], hc["obj"]) and np.array_equal(hg["inside"], hc["inside"])
+    hit = hc["obj"] >= 0
+    assert hit.mean() > 0.9 and np.allclose(hg["dist"][hit], hc["dist"][hit], rtol=1e-12, atol=1e-9)
+
+
 def test_paths_stop_at_the_depth_limit(gpu):
     """Two facing mirrors: every path runs into MAX_DEP = 13 (Raytracer.h:126-133, :303-310): 14 hits traced."""
     s = scenes.FlatScene()
