@@ -75,6 +75,46 @@ def test_near_collide_analytic_scene(gpu):
     assert np.allclose(g["color"][hit], c["color"][hit], rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("layout", ["long_run", "sixteen_runs", "seventeen_runs", "spheres_only", "tilted_only"])
+def test_near_collide_at_the_limits_of_the_run_table(gpu, layout):
+    """The plane / sphere loop walks the objects as runs of one kind, sixteen runs of up to fifteen objects packed in kernel
+    arguments: a run of twenty walls along one axis (split 15 + 5), exactly sixteen runs, seventeen (the general route), a
+    scene of spheres only and one of tilted planes only.  Object, inside flag and distance equal the oracle's ray for ray."""
+    rng = np.random.default_rng(["long_run", "sixteen_runs", "seventeen_runs", "spheres_only", "tilted_only"].index(layout) + 11)
+    s = scenes.FlatScene()
+    def wall(axis):
+        n = np.zeros(3); n[axis] = rng.choice([-1.0, 1.0])
+        s.add_plane(tuple(rng.normal(size=3) * 60), tuple(n), tuple(rng.random(3)), scenes.WHITE_DIFF)
+    def ball():
+        s.add_sphere(float(rng.uniform(3, 20)), tuple(rng.normal(size=3) * 40), tuple(rng.random(3)), scenes.WHITE_DIFF)
+    def tilted():
+        s.add_plane(tuple(rng.normal(size=3) * 60), tuple(rng.normal(size=3)), tuple(rng.random(3)), scenes.WHITE_DIFF)
+    if layout == "long_run":
+        for _ in range(20): wall(1)
+        ball()
+    elif layout in ("sixteen_runs", "seventeen_runs"):
+        for k in range(16 if layout == "sixteen_runs" else 17):
+            (wall(k % 3) if k % 2 == 0 else ball())
+    elif layout == "spheres_only":
+        for _ in range(9): ball()
+    else:
+        for _ in range(5): tilted()
+    s.add_light((0, 50, 0), (1000, 1000, 1000))
+    gpu.set_scene(s)
+    o = _oracle(s)
+    n_rays = 4096
+    org = rng.normal(size=(n_rays, 3)) * 30
+    d = rng.normal(size=(n_rays, 3))
+    d[: n_rays // 8, 1] = 0.0                               # parallel to the y walls
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    g, c = gpu.near_collide(org, d, SEED), o.near_collide(org, d, SEED)
+    assert np.array_equal(g["obj"], c["obj"]) and np.array_equal(g["inside"], c["inside"])
+    hit = c["obj"] >= 0
+    assert hit.sum() > 200
+    assert np.allclose(g["dist"][hit], c["dist"][hit], rtol=1e-12, atol=1e-9)
+    assert np.allclose(g["n"][hit], c["n"][hit], rtol=0, atol=1e-12)
+
+
 def test_near_collide_random_analytic_scenes(gpu):
     """Scene::NearCollide over randomly placed planes and spheres (overlapping spheres, planes through the cloud of
     ray origins, origins inside spheres, rays grazing and parallel to planes, equal objects listed twice so that the
