@@ -371,6 +371,47 @@ __device__ __forceinline__ bool aabb_may_hit_lb(const double* __restrict__ box, 
     return t0 <= t1;
 }
 
+// AABBbox::intersect answered in fp32 wherever fp32 can be sure of the answer.  With no direction component that IsZero,
+// the reference's test says yes exactly when T = max_i entry_i is positive and T <= X = min_i exit_i (entry_i, exit_i: the
+// ray parameters at which the ray crosses into and out of slab i): the face it enters through is the one of the largest
+// entry parameter, and its hit point lies within the other two slabs exactly when their entry parameters are not larger
+// and their exit parameters not smaller.  Each parameter is computed here with a relative error below 1e-6 (two
+// conversions, a reciprocal, a product) and bracketed by that much and by 1e-5 absolute (the reference's own o + t * d
+// carries 1e-16 of the coordinates, divided by a direction component of at least 1e-4): `yes` and a false `open` are
+// certain, and only a ray for which `open` comes back true needs the fp64 test.  With a component that IsZero the reference
+// does not enter through that axis' faces but still holds the hit point to its slab, so it says yes for a subset of the
+// rays the slab test passes: then `yes` is never claimed and `open` is the slab test (a ray exactly parallel gives
+// +-inf or the NaN of 0 * inf, which fminf / fmaxf drop: no constraint).  lb: the lower bound of aabb_entry_lb, the
+// entry parameters moved out by the margin.
+__device__ __forceinline__ void aabb_classify(const double* __restrict__ box, d3 o, d3 d, bool& yes, bool& open, float& lb) {
+    const float W = 1e-6f, A = 1e-5f;
+    float tl = -3.0e38f, th = -3.0e38f, xl = 3.0e38f, xh = 3.0e38f, g = 0.0f, dmin = 3.0e38f;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float df = (float)comp(d, i);
+        const float inv = __builtin_amdgcn_rcpf(df);
+        dmin = fminf(dmin, fabsf(df));
+        const float a = (float)(box[i] - comp(o, i)) * inv, b = (float)(box[3 + i] - comp(o, i)) * inv;
+        const float en = fminf(a, b), ex = fmaxf(a, b);
+        const float enl = fmaf(-fabsf(en), W, en);
+        tl = fmaxf(tl, enl);
+        th = fmaxf(th, fmaf(fabsf(en), W, en));
+        xl = fminf(xl, fmaf(-fabsf(ex), W, ex));
+        xh = fminf(xh, fmaf(fabsf(ex), W, ex));
+        g = fmaxf(g, fmaf(-fabsf(inv), SPPM_PRUNE_MARGIN * 1.001f, enl));
+    }
+    const bool no = (th + A <= 0.0f) || (tl - A > xh + A);
+    yes = (dmin >= 1.001e-4f) && (tl - A > 0.0f) && (th + A <= xl - A);
+    open = !no && !yes;
+    lb = g;
+}
+// The fp64 test for the rays aabb_classify leaves open: rare, so the ray goes through an opaque copy, which keeps the
+// compiler from computing the test's direction predicates ahead of the branch, on every turn of the loops around it.
+__device__ __forceinline__ bool aabb_hit_cold(const double* __restrict__ box, d3 o, d3 d) {
+    asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z));
+    return aabb_hit(box, o, d);
+}
+
 // ------------------------------------------------------------------ bicubic Bernstein evaluation (Bezier.h:69-111), fp32
 // S(u,v) = sum_i sum_k P[4i+k] b_k(u) b_i(v): u runs along the fast index.
 struct f3 { float x, y, z; };
@@ -635,8 +676,11 @@ __device__ __forceinline__ void bezier_coop(const SceneView& S, const DevObject&
         for (int base = 0; base < n_patches; base += 64) {
             int p = first_patch + base + lane;
             float lbf = 0.0f;
-            bool ph = (base + lane < n_patches) && aabb_may_hit_lb(S.patch_box + 6 * p, so, sd, lbf);
-            if (__ballot(ph)) ph = ph && aabb_hit(S.patch_box + 6 * p, so, sd);                // Bezier3::intersect, Bezier.h:176-186
+            bool ph, ph_open;
+            aabb_classify(S.patch_box + 6 * p, so, sd, ph, ph_open, lbf);                      // Bezier3::intersect, Bezier.h:176-186
+            ph = ph && (base + lane < n_patches);
+            ph_open = ph_open && (base + lane < n_patches);
+            if (__ballot(ph_open)) ph = ph || (ph_open && aabb_hit_cold(S.patch_box + 6 * p, so, sd));
             // lb >= 0, so the bit patterns order like the values and the selection below runs on scalars
             uint32_t lbb = ph ? __float_as_uint(lbf) : 0xffffffffu;
             if (S.sub_box && __ballot(ph)) subbox_prune(S.sub_box, first_patch + base, so, sd, ph, lbb);
@@ -807,11 +851,15 @@ __device__ __forceinline__ void bezier_nearest_coop(const SceneView& S, bool act
         const DevObject& ob = S.objs[a];
         if (S.n_bez < 0 && __builtin_amdgcn_readfirstlane(ob.type) != OBJ_BEZIER) continue;
         // The object's box (Bezier.h:244) is tested by every lane in every turn of the trace loop, and three rays in a
-        // thousand enter it: the fp32 may-hit test answers first (a "no" is certain), and the reference's fp64 test with its
-        // three divisions runs only in a wave where some lane says maybe.  bmin and bmax lie side by side: one box of six.
+        // thousand enter it: the fp32 test answers wherever it is sure (aabb_classify), and the reference's fp64 test with its
+        // three divisions runs only in a wave where some lane's ray grazes the box.  bmin and bmax lie side by side: one box
+        // of six.
         float obj_lb;
-        bool need = active && aabb_may_hit_lb(ob.bmin, o, d, obj_lb);
-        if (__ballot(need)) need = need && aabb_hit(ob.bmin, o, d);
+        bool need, need_open;
+        aabb_classify(ob.bmin, o, d, need, need_open, obj_lb);
+        need = need && active;
+        need_open = need_open && active;
+        if (__ballot(need_open)) need = need || (need_open && aabb_hit_cold(ob.bmin, o, d));
         float t, u, v;
         int patch;
         bezier_coop(S, ob, need, o, d, path_hash, vertex, (float)nr.dist, t, u, v, patch, newton_calls);
@@ -834,8 +882,11 @@ __device__ __forceinline__ void bezier_patch_masks(const SceneView& S, bool acti
         if (S.n_bez < 0 && __builtin_amdgcn_readfirstlane(ob.type) != OBJ_BEZIER) continue;
         const int n_patches = __builtin_amdgcn_readfirstlane(ob.n_patches), first_patch = __builtin_amdgcn_readfirstlane(ob.first_patch);
         float obj_lb;
-        bool need = active && aabb_may_hit_lb(ob.bmin, o, d, obj_lb);                  // as in bezier_nearest_coop
-        if (__ballot(need)) need = need && aabb_hit(ob.bmin, o, d);
+        bool need, need_open;
+        aabb_classify(ob.bmin, o, d, need, need_open, obj_lb);                         // as in bezier_nearest_coop
+        need = need && active;
+        need_open = need_open && active;
+        if (__ballot(need_open)) need = need || (need_open && aabb_hit_cold(ob.bmin, o, d));
         uint64_t m = __ballot(need);
         while (m) {
             int src = __ffsll((unsigned long long)m) - 1;
