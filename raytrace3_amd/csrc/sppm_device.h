@@ -253,6 +253,33 @@ __device__ __forceinline__ d3 rand_refl(d3 n, double u1, double u2) {
     const d3 b = cross(a, n);
     return get_unit_near1(n * cost + (b * cp + a * sp) * sint);
 }
+// sin and cos of phi = 2 PI k / 2^24 for the 24-bit draw k behind a uniform u2 = k / 2^24 (PI: the reference's constant,
+// SPPM_PI): the top eight bits pick (sin, cos) of 2 PI j / 256 from a table of 256 pairs, correct to the last place (made on
+// the host in extended precision, copied to LDS by the photon kernel), the low sixteen an angle x < 2 PI / 256 whose Taylor series stop at x^7 / x^6 (the
+// next terms are below 4e-18), and the two meet by the addition theorems.  About 25 instructions and one LDS read where the
+// library's sincos, with its argument reduction for any double, takes 156; the results differ from sincos(fl(2 PI u2)) by
+// a few 1e-16, which is what rounding phi to a double already moves them by.
+#define SPPM_SINCOS_TAB 256
+__device__ __forceinline__ void sincos_2pi_u24(SPPM_LDS(double)* tab, uint32_t k, double& s, double& c) {
+    const uint32_t hi = k >> 16, lo = k & 0xffffu;
+    const double sh = tab[2 * hi], ch = tab[2 * hi + 1];
+    const double x = (double)lo * (2.0 * SPPM_PI / 16777216.0), x2 = x * x;
+    const double sl = x * fma(x2, fma(x2, fma(x2, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
+    const double cl = fma(x2, fma(x2, fma(x2, -1.0 / 720.0, 1.0 / 24.0), -0.5), 1.0);
+    s = fma(sh, cl, ch * sl);
+    c = fma(ch, cl, -(sh * sl));
+}
+// rand_refl with phi's sine and cosine from the table: k2 is the draw behind u2.
+__device__ __forceinline__ d3 rand_refl_tab(d3 n, double u1, uint32_t k2, SPPM_LDS(double)* tab) {
+    const double cost = sqrt_nr(u1), sint = sqrt_nr(1.0 - u1);
+    const double phi = 2 * SPPM_PI * ((double)k2 * (1.0 / 16777216.0));
+    double sp, cp;
+    sincos_2pi_u24(tab, k2, sp, cp);
+    if (fabs(phi) < SPPM_EPS) { sp = 0.0; cp = 1.0; }      // Vec3::rotated returns its input (Vec3.h:101)
+    const d3 a = get_anormal(n);
+    const d3 b = cross(a, n);
+    return get_unit_near1(n * cost + (b * cp + a * sp) * sint);
+}
 __device__ __forceinline__ d3 refracted(d3 I, d3 N, double n) {                            // Vec3.h:124-134
     double cosI = -dot(N, I);
     double cosR2 = 1 - (1 - cosI * cosI) * (n * n);

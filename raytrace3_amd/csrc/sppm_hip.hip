@@ -254,6 +254,7 @@ struct TraceParams {
     uint32_t* hcount;                                                         // HitPoints per grid bucket (the histogram of their counting sort)
     // photon pass
     const DevLight* lights; int n_lights; uint32_t per_round;
+    const double* sincos_tab;                 // SPPM_SINCOS_TAB pairs (sin, cos) of 2 PI j / SPPM_SINCOS_TAB, copied to LDS by the photon kernel
     Deposit* dep; unsigned long long* n_dep; unsigned long long dep_cap;
     uint32_t* dcount; GridParams grid;
     const uint8_t* occ;                       // one byte per bucket: some HitPoint lies within one cell of a cell of that bucket
@@ -304,7 +305,10 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
     // waiting for a vector load from global memory at the head of a turn of the loop.
     DevLight* lds_lights = (DevLight*)((double*)((char*)lds_scene + (IN_LDS ? ((sp.blob_bytes + 15) & ~15) : 0)) + 4 * (3 * 128));
     const bool lights_in_lds = MODE == MODE_PHOTON && tp.n_lights <= TRACE_LDS_LIGHTS;
+    // and behind the lights the table of sincos_2pi_u24 (the diffuse bounce's angle about the normal)
+    double* lds_sincos = (double*)(lds_lights + TRACE_LDS_LIGHTS);
     if (MODE == MODE_PHOTON) {
+        for (uint32_t i = threadIdx.x; i < 2u * SPPM_SINCOS_TAB; i += blockDim.x) lds_sincos[i] = tp.sincos_tab[i];
         if (lights_in_lds) {
             const uint32_t* src = (const uint32_t*)tp.lights;
             uint32_t* dst = (uint32_t*)lds_lights;
@@ -600,7 +604,8 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
 #ifdef ABLATE_BOUNCE
                     nd = get_unit(hit.n + mk(rng_u01(ds, 0) - 0.5, rng_u01(ds, 1) - 0.5, 0.1));
 #else
-                    nd = rand_refl(hit.n, rng_u01(ds, 0), rng_u01(ds, 1));
+                    if (MODE == MODE_PHOTON) nd = rand_refl_tab(hit.n, rng_u01(ds, 0), rng_bits(ds, 1), (SPPM_LDS(double)*)lds_sincos);
+                    else nd = rand_refl(hit.n, rng_u01(ds, 0), rng_u01(ds, 1));
 #endif
                 } else if (lobe == F_REFL || (lobe == 0 && ob.diffr + ob.reflr > r)) {    // REFL, Raytracer.h:177-181
                     nd = get_unit_near1(get_refl(d, hit.n));
@@ -1450,6 +1455,7 @@ struct sppm_ctx {
     DevBuf<float> sub_box;                     // boxes of the sub-patches (subbox_prune); SPPM_SUBBOX=0: not used
     bool use_sub_box = true;
     DevBuf<DevLight> lights; int n_lights = 0;
+    DevBuf<double> sincos_tab;            // table of sincos_2pi_u24, filled once in sppm_create
     // eye pass
     bool have_eye = false;
     sppm_camera cam{};
@@ -1659,6 +1665,24 @@ int sppm_create(sppm_ctx** out, int device_id) {
     }
     (void)hipMemset(ctx->ctl.p, 0, ctx->ctl_words() * sizeof(unsigned long long));
     (void)hipMemset(ctx->counters.p, 0, sizeof(DevCounters));
+    {
+        // sin and cos of 2 PI j / 256 in the host's extended precision, rounded once to double; PI is the reference's
+        // seven-digit constant (Vec3.h:7), so a full turn of phi is not quite a full circle and no entry is an exact zero
+        double tab[2 * SPPM_SINCOS_TAB];
+        const long double two_pi = (long double)(2.0 * SPPM_PI);
+        for (int j = 0; j < SPPM_SINCOS_TAB; j++) {
+            const long double a = two_pi * (long double)j / (long double)SPPM_SINCOS_TAB;
+            tab[2 * j] = (double)sinl(a);
+            tab[2 * j + 1] = (double)cosl(a);
+        }
+        if (ctx->sincos_tab.reserve(2 * SPPM_SINCOS_TAB) != hipSuccess ||
+            hipMemcpy(ctx->sincos_tab.p, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) {
+            ctx->ctl.release(); ctx->counters.release(); ctx->sincos_tab.release();
+            (void)hipStreamDestroy(ctx->own_stream);
+            delete ctx;
+            return SPPM_E_DEVICE;
+        }
+    }
     if (device_id < 64) g_live_contexts[device_id].fetch_add(1);
     *out = ctx;
     return SPPM_OK;
@@ -1669,7 +1693,7 @@ void sppm_destroy(sppm_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->pw_q.release(); ctx->pw_c.release(); ctx->sub_box.release();
-    ctx->blob.release(); ctx->texels.release(); ctx->lights.release();
+    ctx->blob.release(); ctx->texels.release(); ctx->lights.release(); ctx->sincos_tab.release();
     ctx->raw.release(); ctx->park[0].release(); ctx->park[1].release(); ctx->ntask[0].release(); ctx->ntask[1].release(); ctx->nres.release();
     ctx->hist.release(); ctx->hstart.release();
     ctx->hp_rec.release(); ctx->hp_tao.release(); ctx->hp_meta.release(); ctx->hp_r2.release(); ctx->sorted_of_raw.release();
@@ -1995,8 +2019,8 @@ static int close_chunks(sppm_ctx* ctx, Deposit* dep, RawHit* hits, uint64_t cap)
 
 template <int MODE>
 static void launch_trace(sppm_ctx* ctx, bool coop, int blocks, const SceneParams& sp, const TraceParams& tp) {
-    // dynamic LDS: the scene tables, then (photon pass) 4 waves x 128 emission directions and the first lights
-    const size_t lds = (ctx->scene_in_lds ? (((size_t)ctx->blob_bytes + 15) & ~(size_t)15) : 0) + (MODE == MODE_PHOTON ? 4 * 128 * 3 * sizeof(double) + TRACE_LDS_LIGHTS * sizeof(DevLight) : 0);
+    // dynamic LDS: the scene tables, then (photon pass) 4 waves x 128 emission directions, the first lights and the sine table
+    const size_t lds = (ctx->scene_in_lds ? (((size_t)ctx->blob_bytes + 15) & ~(size_t)15) : 0) + (MODE == MODE_PHOTON ? 4 * 128 * 3 * sizeof(double) + TRACE_LDS_LIGHTS * sizeof(DevLight) + 2 * SPPM_SINCOS_TAB * sizeof(double) : 0);
     if (!ctx->scene_in_lds) hipLaunchKernelGGL((k_trace<MODE, true, false>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);   // coop_only
     else if (coop) hipLaunchKernelGGL((k_trace<MODE, true, true>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
     else hipLaunchKernelGGL((k_trace<MODE, false, true>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
@@ -2279,6 +2303,7 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
 static void fill_photon_params(sppm_ctx* ctx, TraceParams& tp, uint32_t per_round, uint64_t dep_cap, uint64_t seed, uint32_t replica,
                                DevCounters* counters) {
     tp.lights = ctx->lights.p; tp.n_lights = ctx->n_lights; tp.per_round = per_round;
+    tp.sincos_tab = ctx->sincos_tab.p;
     tp.dep = ctx->dep.p; tp.n_dep = ctx->scalars() + SC_DEP; tp.dep_cap = dep_cap;
     tp.dcount = ctx->dcount(); tp.grid = ctx->grid; tp.counters = counters;
     tp.occ = ctx->dep_filter ? ctx->occ() : nullptr;
