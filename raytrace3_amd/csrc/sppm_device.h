@@ -377,27 +377,6 @@ __device__ __forceinline__ float aabb_entry_lb(const double* __restrict__ box, d
     return t0;
 }
 
-// Both at once, for the loop that takes one ray at a time through an object's patches: can the ray meet the box grown by
-// the margin at all (fp32 slab test, every slab distance moved outwards by more than its rounding error, so a "no" is
-// certain whatever the size of the coordinates), and if so the lower bound of aabb_entry_lb.  AABBbox::intersect can only
-// say yes where this does, so the fp64 test is run only for rays that some box may be met by: most rays that enter the
-// object's box pass between its patches.
-__device__ __forceinline__ bool aabb_may_hit_lb(const double* __restrict__ box, d3 o, d3 d, float& lb) {
-    float t0 = 0.0f, t1 = 3.0e38f;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        // +-inf for a ray parallel to the axis: outside the slab the interval comes out empty, inside unbounded, and the
-        // NaN of 0 * inf or inf - inf is dropped by fminf / fmaxf (no constraint)
-        const float inv = __builtin_amdgcn_rcpf((float)comp(d, i));
-        const float a = ((float)(box[i] - comp(o, i)) - SPPM_PRUNE_MARGIN) * inv, b = ((float)(box[3 + i] - comp(o, i)) + SPPM_PRUNE_MARGIN) * inv;
-        const float lo = fminf(a, b), hi = fmaxf(a, b);
-        t0 = fmaxf(t0, fmaf(-fabsf(lo), 1e-6f, lo));
-        t1 = fminf(t1, fmaf(fabsf(hi), 1e-6f, hi));
-    }
-    lb = t0;
-    return t0 <= t1;
-}
-
 // AABBbox::intersect answered in fp32 wherever fp32 can be sure of the answer.  With no direction component that IsZero,
 // the reference's test says yes exactly when T = max_i entry_i is positive and T <= X = min_i exit_i (entry_i, exit_i: the
 // ray parameters at which the ray crosses into and out of slab i): the face it enters through is the one of the largest
