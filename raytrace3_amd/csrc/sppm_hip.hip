@@ -279,7 +279,9 @@ struct TraceParams {
 // box culls leave patches to solve is PARKED: its state and one task per patch go to queues,
 // k_newton solves all tasks of the round at full occupancy, and the next launch resumes the ray
 // from its record.  This keeps the 50 x 10 Newton iterations out of the divergent path loop.
-template <int MODE, bool COOP, bool IN_LDS>
+// BEZ = false: a scene without Bezier objects; the kernel then holds no Bezier stage (its registers and spilled scalars cost
+// the loop time even where it never runs).
+template <int MODE, bool COOP, bool IN_LDS, bool BEZ = true>
 __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC : TRACE_COOP_OCC) : 3) k_trace(SceneParams sp, TraceParams tp) {
     const unsigned long long n_resume = tp.resume ? min(*tp.n_resume_dev, tp.park_cap) : 0ull;   // records beyond the capacity were never written
     const unsigned long long total = n_resume + tp.fresh_count;
@@ -442,7 +444,7 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
             analytic_nearest(S, tracing, o, d, a);
             STAMP(1);
             if (COOP) {
-                bezier_nearest_coop(S, tracing, o, d, path_hash, nvertex, a, ncalls);
+                if (BEZ) bezier_nearest_coop(S, tracing, o, d, path_hash, nvertex, a, ncalls);
                 STAMP(2);
             } else {
                 bezier_patch_masks(S, tracing, o, d, words);
@@ -2022,6 +2024,7 @@ static void launch_trace(sppm_ctx* ctx, bool coop, int blocks, const SceneParams
     // dynamic LDS: the scene tables, then (photon pass) 4 waves x 128 emission directions, the first lights and the sine table
     const size_t lds = (ctx->scene_in_lds ? (((size_t)ctx->blob_bytes + 15) & ~(size_t)15) : 0) + (MODE == MODE_PHOTON ? 4 * 128 * 3 * sizeof(double) + TRACE_LDS_LIGHTS * sizeof(DevLight) + 2 * SPPM_SINCOS_TAB * sizeof(double) : 0);
     if (!ctx->scene_in_lds) hipLaunchKernelGGL((k_trace<MODE, true, false>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);   // coop_only
+    else if (coop && sp.n_patches == 0) hipLaunchKernelGGL((k_trace<MODE, true, true, false>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
     else if (coop) hipLaunchKernelGGL((k_trace<MODE, true, true>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
     else hipLaunchKernelGGL((k_trace<MODE, false, true>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
 }
