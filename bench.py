@@ -91,11 +91,19 @@ SIMD_CYCLES_PER_S = N_CU * N_SIMD * CLOCK_HZ                 # what the vector u
 PEAK_TLANE_CYCLES = SIMD_CYCLES_PER_S * 64 / 1e12            # ... and in lane-cycles: 64 lanes per SIMD-cycle of a busy vector unit
 
 
+# the photon and eye trace kernels of a scene with Bezier objects, as profiles name them (template instances up to the
+# r2_07 sets, kernels of their own since)
+TRACE_PHOTON = ("k_trace_photon_bez", "k_trace<1")
+TRACE_EYE = ("k_trace_eye_bez", "k_trace<0")
+
+
 def _kernel(d, name):
-    """The summary's entry for a kernel, template arguments or not (k_gather, k_gather<true>)."""
-    for k, v in d.items():
-        if k == name or k.startswith(name + "<") or (name[-2:] in ("<0", "<1") and k.startswith(name)):
-            return v
+    """The summary's entry for a kernel, template arguments or not (k_gather, k_gather<true>); name may be a tuple of
+    alternatives, the first that is present wins."""
+    for n in (name if isinstance(name, tuple) else (name,)):
+        for k, v in d.items():
+            if k == n or k.startswith(n + "<") or (n[-2:] in ("<0", "<1") and k.startswith(n)):
+                return v
     return {}
 
 
@@ -114,7 +122,7 @@ def committed_profile(shared):
                 d = json.load(fh)
         except (OSError, ValueError):
             continue
-        if not any(k.startswith("k_trace<1") for k in d):
+        if not _kernel(d, TRACE_PHOTON):
             continue
         share = {}
         try:
@@ -288,12 +296,12 @@ def main():
 
         # ---- dominant kernel: the photon trace (persistent wavefronts, fp64 ray state): bound by vector-instruction issue
         trace_s = alone["photon_trace_ms"] * alone_steps / tl / 1e3
-        tc = _kernel(pk, "k_trace<1")
+        tc = _kernel(pk, TRACE_PHOTON)
         tv = valu_fields(tc, trace_s) if tc else None
         lane_cycles = tv.get("lane_cycles") if tv else None
         roofline = {
             "kernel": "k_trace<MODE_PHOTON> (photon emission + PhotonTrace on persistent wavefronts; fp64 ray state, in-wave Bezier solves)",
-            "share_of_gpu_time": next((v for k, v in share.items() if k.startswith("k_trace<1")), None),
+            "share_of_gpu_time": next((v for k, v in share.items() if k.startswith(TRACE_PHOTON)), None),
             "bound": "valu", "unit": "Tlane-cycle/s", "peak": PEAK_TLANE_CYCLES,
             "achieved": lane_cycles / trace_s / 1e12 if lane_cycles else None,
             "frac": lane_cycles / trace_s / 1e12 / PEAK_TLANE_CYCLES if lane_cycles else None,
@@ -337,7 +345,7 @@ def main():
         # ---- the GPU as a whole over the timed region: with several iterations in flight the kernels of different iterations
         # share the vector units, and no single kernel's figure says how busy those are
         iter_s = elapsed / args.steps
-        big = [_kernel(pk, "k_trace<1"), _kernel(pk, "k_trace<0"), gc, gs]      # one launch each per iteration
+        big = [_kernel(pk, TRACE_PHOTON), _kernel(pk, TRACE_EYE), gc, gs]      # one launch each per iteration
         if all(k.get("SQ_ACTIVE_INST_VALU") for k in big) and iter_s > 0:
             act = sum(k["SQ_ACTIVE_INST_VALU"] for k in big)
             thr = sum(k.get("SQ_THREAD_CYCLES_VALU", 0.0) for k in big)

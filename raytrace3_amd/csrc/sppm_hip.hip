@@ -282,7 +282,7 @@ struct TraceParams {
 // BEZ = false: a scene without Bezier objects; the kernel then holds no Bezier stage (its registers and spilled scalars cost
 // the loop time even where it never runs).
 template <int MODE, bool COOP, bool IN_LDS, bool BEZ = true>
-__global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC : TRACE_COOP_OCC) : 3) k_trace(SceneParams sp, TraceParams tp) {
+__device__ __forceinline__ void trace_body(const SceneParams& sp, const TraceParams& tp) {
     const unsigned long long n_resume = tp.resume ? min(*tp.n_resume_dev, tp.park_cap) : 0ull;   // records beyond the capacity were never written
     const unsigned long long total = n_resume + tp.fresh_count;
     // the host sizes a resume launch without knowing its count: workgroups beyond the work leave at once
@@ -669,6 +669,28 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
         flush_uniform(&tp.counters->photons, nphot);
         flush_uniform(&tp.counters->stored, nstored);
     }
+}
+
+template <int MODE, bool COOP, bool IN_LDS, bool BEZ = true>
+__global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC : TRACE_COOP_OCC) : 3) k_trace(SceneParams sp, TraceParams tp) {
+    trace_body<MODE, COOP, IN_LDS, BEZ>(sp, tp);
+}
+// The two kernels the reference's scene runs, under names of their own so that each can be held to a register count
+// (the attribute counts register PAIRS of the unified file here: 116 means 232 VGPRs).  Left alone the photon kernel takes
+// 244, i.e. 248 allocated: beside three gather workgroups of 80 that leaves 24 registers per lane of a SIMD, and the small
+// kernels between the passes (scans, HitPoint scatter, occupancy, resolve: 32 to 40 registers) wait for a workgroup to
+// leave.  At 232 nothing spills and they fit in.
+#ifndef TRACE_PHOTON_VGPRS
+#define TRACE_PHOTON_VGPRS 116
+#endif
+#ifndef TRACE_EYE_VGPRS
+#define TRACE_EYE_VGPRS 0
+#endif
+__global__ void __launch_bounds__(256, TRACE_COOP_OCC) __attribute__((amdgpu_num_vgpr(TRACE_PHOTON_VGPRS))) k_trace_photon_bez(SceneParams sp, TraceParams tp) {
+    trace_body<MODE_PHOTON, true, true, true>(sp, tp);
+}
+__global__ void __launch_bounds__(256, TRACE_EYE_OCC) __attribute__((amdgpu_num_vgpr(TRACE_EYE_VGPRS))) k_trace_eye_bez(SceneParams sp, TraceParams tp) {
+    trace_body<MODE_EYE, true, true, true>(sp, tp);
 }
 
 // Bezier3::newton (Bezier.h:112-159) for the parked rays of a round: one wave per ray at a time, on
@@ -2025,7 +2047,8 @@ static void launch_trace(sppm_ctx* ctx, bool coop, int blocks, const SceneParams
     const size_t lds = (ctx->scene_in_lds ? (((size_t)ctx->blob_bytes + 15) & ~(size_t)15) : 0) + (MODE == MODE_PHOTON ? 4 * 128 * 3 * sizeof(double) + TRACE_LDS_LIGHTS * sizeof(DevLight) + 2 * SPPM_SINCOS_TAB * sizeof(double) : 0);
     if (!ctx->scene_in_lds) hipLaunchKernelGGL((k_trace<MODE, true, false>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);   // coop_only
     else if (coop && sp.n_patches == 0) hipLaunchKernelGGL((k_trace<MODE, true, true, false>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
-    else if (coop) hipLaunchKernelGGL((k_trace<MODE, true, true>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
+    else if (coop && MODE == MODE_PHOTON) hipLaunchKernelGGL(k_trace_photon_bez, dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
+    else if (coop) hipLaunchKernelGGL(k_trace_eye_bez, dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
     else hipLaunchKernelGGL((k_trace<MODE, false, true>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
 }
 static int launch_trace_mode(sppm_ctx* ctx, int mode, bool coop, int blocks, const TraceParams& tp) {
