@@ -410,6 +410,19 @@ def test_two_lights_share_the_per_light_normaliser(gpu):
     _image_parity(gpu.resolve(), o.resolve(), frac=0.995)
 
 
+def test_a_scene_of_bezier_objects_only(gpu):
+    """No plane and no sphere: the plane / sphere loop has no run to walk and every hit is a patch hit (two teapots in empty
+    space, the light between them; most photons and most eye rays leave without hitting anything).  Both passes against the
+    fp32-Newton oracle and the fp64 one."""
+    s = scenes.FlatScene()
+    s.add_bezier((20, 0, 120), 4, scenes.TEAPOT_BPT, (0, .999, .999), scenes.WHITE_DIFF, scenes.teapot_transform())
+    s.add_bezier((60, 0, 110), 4, scenes.TEAPOT_BPT, (.9, .9, .2), scenes.WHITE_DIFF, scenes.teapot_transform())
+    s.add_light((42, 30, 130), (5000, 5000, 5000))
+    assert all(o["type"] == 2 for o in s.objects)
+    _bezier_case(gpu, s, scenes.default_camera(400, 300), 200, 100, 0, first_bezier_obj=0)
+    assert gpu.counters()["hitpoints"] > 2000
+
+
 def test_more_runs_and_lights_than_the_packed_forms_hold(gpu):
     """The trace kernels take the objects' kinds as runs packed in two kernel arguments (sixteen runs) and the first sixteen
     lights from LDS; a scene beyond both limits goes through the general routes: 24 objects whose kinds alternate (planes
