@@ -18,7 +18,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + '/abtr_' + tag + '_*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if 'k_gather<' in k or 'k_trace<1' in k or 'k_gather_split' in k:
+        if 'k_gather<' in k or 'k_trace_photon' in k or 'k_trace<1' in k or 'k_gather_split' in k:
             acc[k.split('(')[0][-28:]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, v in sorted(acc.items()):
     m = {c: sum(x) / len(x) for c, x in v.items()}
