@@ -692,6 +692,15 @@ __global__ void __launch_bounds__(256, TRACE_COOP_OCC) __attribute__((amdgpu_num
 __global__ void __launch_bounds__(256, TRACE_EYE_OCC) __attribute__((amdgpu_num_vgpr(TRACE_EYE_VGPRS))) k_trace_eye_bez(SceneParams sp, TraceParams tp) {
     trace_body<MODE_EYE, true, true, true>(sp, tp);
 }
+// The photon kernel of a scene without Bezier objects takes 198 registers; held to 160 it spills 31 values and runs 3 %
+// longer by itself, but one such wave leaves a SIMD room for four gather waves (or two of them for two): the glass-ball
+// caustic scene, 48 photon batches and a long gather per iteration, gains 8 % as a whole.
+#ifndef TRACE_PLAIN_VGPRS
+#define TRACE_PLAIN_VGPRS 80
+#endif
+__global__ void __launch_bounds__(256, TRACE_COOP_OCC) __attribute__((amdgpu_num_vgpr(TRACE_PLAIN_VGPRS))) k_trace_photon_plain(SceneParams sp, TraceParams tp) {
+    trace_body<MODE_PHOTON, true, true, false>(sp, tp);
+}
 
 // Bezier3::newton (Bezier.h:112-159) for the parked rays of a round: one wave per ray at a time, on
 // long-lived waves.  The lanes look up the boxes of the ray's tasks (one task = one patch whose box the ray
@@ -2046,6 +2055,7 @@ static void launch_trace(sppm_ctx* ctx, bool coop, int blocks, const SceneParams
     // dynamic LDS: the scene tables, then (photon pass) 4 waves x 128 emission directions, the first lights and the sine table
     const size_t lds = (ctx->scene_in_lds ? (((size_t)ctx->blob_bytes + 15) & ~(size_t)15) : 0) + (MODE == MODE_PHOTON ? 4 * 128 * 3 * sizeof(double) + TRACE_LDS_LIGHTS * sizeof(DevLight) + 2 * SPPM_SINCOS_TAB * sizeof(double) : 0);
     if (!ctx->scene_in_lds) hipLaunchKernelGGL((k_trace<MODE, true, false>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);   // coop_only
+    else if (coop && sp.n_patches == 0 && MODE == MODE_PHOTON) hipLaunchKernelGGL(k_trace_photon_plain, dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
     else if (coop && sp.n_patches == 0) hipLaunchKernelGGL((k_trace<MODE, true, true, false>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
     else if (coop && MODE == MODE_PHOTON) hipLaunchKernelGGL(k_trace_photon_bez, dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
     else if (coop) hipLaunchKernelGGL(k_trace_eye_bez, dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
@@ -2393,7 +2403,8 @@ int sppm_synchronize(sppm_ctx* ctx) {
 static int launch_gather(sppm_ctx* ctx, const uint32_t* dstart, const uint32_t* dlen, const Deposit* over, uint64_t dep_cap, bool fixed_r2) {
     tic(ctx, PH_GATHER);
     const uint64_t tiles = (ctx->n_hp + GATHER_TILE - 1) / GATHER_TILE;
-    const int gather_bpc = ctx->gather_blocks_per_cu > 0 ? ctx->gather_blocks_per_cu : (shares_gpu(ctx->device) ? 3 : 5);
+    // beside a trace wave of 232 registers a SIMD has room for three gather waves, beside one of 160 (no Bezier objects) for four
+    const int gather_bpc = ctx->gather_blocks_per_cu > 0 ? ctx->gather_blocks_per_cu : (shares_gpu(ctx->device) ? (ctx->n_patches == 0 ? 4 : 3) : 5);
     const int blocks = (int)std::max<uint64_t>(8, std::min<uint64_t>((uint64_t)ctx->num_cu * gather_bpc, ((tiles + 3) / 4 + 7) / 8 * 8));
     const uint32_t piece_cap = 1u << 20;
     HIPCHK(ctx->pieces.reserve(piece_cap));
