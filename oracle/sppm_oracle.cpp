@@ -812,18 +812,40 @@ void oracle_camera_emit(const sppm_camera* cam, int row, int col, double* org3, 
     put3(dir3, GetUnit(d));
 }
 
-int oracle_eye_pass(oracle_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t replica) {
-    if (!ctx || !cam) return SPPM_E_INVALID;
+int oracle_eye_pass_rows(oracle_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t replica, int row_begin,
+                         int row_end) {
+    if (!ctx || !cam || row_begin < 0 || row_end > cam->h || row_begin > row_end) return SPPM_E_INVALID;
     ctx->cam = *cam; ctx->have_cam = true;
     ctx->Hvec.clear();
     ctx->cnt = sppm_counters{};
-    for (int i = 0; i < cam->h; i++)                                     // GetHitPoint, Raytracer.h:102-116
+    for (int i = row_begin; i < row_end; i++)                            // GetHitPoint, Raytracer.h:102-116
         for (int j = 0; j < cam->w; j++) {
             double o[3], d[3];
             oracle_camera_emit(cam, i, j, o, d);
             ctx->ViewTrace(v3(o), v3(d), 0, V3(1, 1, 1), i, j, 0, seed, replica);
         }
     ctx->cnt.hitpoints = ctx->Hvec.size();
+    ctx->grid.clear(); ctx->kd.clear();
+    return SPPM_OK;
+}
+
+int oracle_eye_pass(oracle_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t replica) {
+    if (!ctx || !cam) return SPPM_E_INVALID;
+    return oracle_eye_pass_rows(ctx, cam, seed, replica, 0, cam->h);
+}
+
+int oracle_set_hitpoints(oracle_ctx* ctx, const sppm_camera* cam, const sppm_hitpoint* in, uint64_t n) {
+    if (!ctx || !cam || (n && !in)) return SPPM_E_INVALID;
+    ctx->cam = *cam; ctx->have_cam = true;
+    ctx->cnt = sppm_counters{};
+    ctx->Hvec.resize(n);
+    for (uint64_t i = 0; i < n; i++) {
+        const sppm_hitpoint& s = in[i];
+        HitPoint& h = ctx->Hvec[i];
+        h.pos = v3(s.pos); h.n = v3(s.n); h.v = v3(s.v); h.wgt = v3(s.wgt); h.tao = v3(s.tao);
+        h.R2 = s.R2; h.obj = s.obj; h.x = s.x; h.y = s.y; h.node = s.node; h.N = s.N; h.newN = s.newN;
+    }
+    ctx->cnt.hitpoints = n;
     ctx->grid.clear(); ctx->kd.clear();
     return SPPM_OK;
 }

@@ -36,6 +36,15 @@ int oracle_set_radius_update(oracle_ctx* ctx, int32_t initial_n, uint32_t rounds
 
 int oracle_set_scene(oracle_ctx* ctx, const sppm_scene* scene);
 int oracle_eye_pass(oracle_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t replica);
+/* The rows [row_begin, row_end) of GetHitPoint's outer loop (Raytracer.h:105): with counter-based streams a pixel's
+ * HitPoints do not depend on the pixels before it, so strips made by several contexts on several host threads,
+ * concatenated in row order and handed to oracle_set_hitpoints, are the HitPoints of oracle_eye_pass. */
+int oracle_eye_pass_rows(oracle_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t replica,
+                         int row_begin, int row_end);
+/* Replace the context's HitPoints by the given records (as oracle_get_hitpoints writes them) and reset its tallies:
+ * lets each of several contexts run a range of the photons (photon_begin / photon_count) over ALL HitPoints; the
+ * pass is linear in tao and newN, so the contexts' resolved images and tallies add up to the serial pass. */
+int oracle_set_hitpoints(oracle_ctx* ctx, const sppm_camera* cam, const sppm_hitpoint* in, uint64_t n);
 
 #define ORACLE_GATHER_GRID 0    /* exact uniform-grid radius search */
 #define ORACLE_GATHER_BRUTE 1   /* all pairs */

@@ -24,6 +24,8 @@ SYMBOLS = {
     "oracle_set_radius_update": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint32]),
     "oracle_set_scene": (C.c_int, [C.c_void_p, C.POINTER(abi.Scene)]),
     "oracle_eye_pass": (C.c_int, [C.c_void_p, C.POINTER(abi.Camera), C.c_uint64, C.c_uint32]),
+    "oracle_eye_pass_rows": (C.c_int, [C.c_void_p, C.POINTER(abi.Camera), C.c_uint64, C.c_uint32, C.c_int, C.c_int]),
+    "oracle_set_hitpoints": (C.c_int, [C.c_void_p, C.POINTER(abi.Camera), C.c_void_p, C.c_uint64]),
     "oracle_photon_pass": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int]),
     "oracle_resolve": (C.c_int, [C.c_void_p, _D, C.c_int]),
     "oracle_get_hitpoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
@@ -98,6 +100,15 @@ class OracleContext:
         self.cam = cam
         assert self.lib.oracle_eye_pass(self._ctx, C.byref(cam), seed, replica) == 0
 
+    def eye_pass_rows(self, cam, seed, row_begin, row_end, replica=0):
+        self.cam = cam
+        assert self.lib.oracle_eye_pass_rows(self._ctx, C.byref(cam), seed, replica, row_begin, row_end) == 0
+
+    def set_hitpoints(self, cam, hp):
+        self.cam = cam
+        hp = np.ascontiguousarray(hp, dtype=abi.HITPOINT_DTYPE)
+        assert self.lib.oracle_set_hitpoints(self._ctx, C.byref(cam), hp.ctypes.data_as(C.c_void_p), len(hp)) == 0
+
     def photon_pass(self, rounds, per_round, seed, replica=0, photon_begin=0, photon_count=0, mode=GATHER_GRID):
         assert self.lib.oracle_photon_pass(self._ctx, rounds, per_round, photon_begin, photon_count, seed, replica, mode) == 0
 
@@ -144,6 +155,117 @@ class OracleContext:
                                              dp(out), cap, C.byref(n))
         assert rc == 0, rc
         return out[:n.value]
+
+
+class ParallelOracle:
+    """The serial oracle driven over host threads for the sizes one thread does not finish in seconds (1920 x 1080 with
+    128 patches, 50 M photons).  Nothing is restated: every piece of work is a call of the serial oracle.  The eye pass
+    is cut into strips of rows (counter-based streams: a pixel's HitPoints do not depend on the pixels before it) whose
+    HitPoints are concatenated in row order, i.e. in the order of OracleContext.eye_pass; every worker context then holds
+    ALL HitPoints and runs ranges of the photon indices, and since the pass is linear in tao and newN the workers'
+    images, per-HitPoint counts and tallies add up to the serial pass (tests/test_oracle_kat.py holds the two against
+    each other; the fp64 sums differ in their order only).  ctypes releases the interpreter lock during a call."""
+
+    def __init__(self, threads, newton_fp32=False):
+        self.lib = load()
+        self.parts = [OracleContext(self.lib, newton_fp32=newton_fp32) for _ in range(max(1, int(threads)))]
+        self.cam = None
+        self._eye, self._hp = {}, None
+
+    def close(self):
+        for p in self.parts:
+            p.close()
+
+    def set_scene(self, scene):
+        for p in self.parts:
+            p.set_scene(scene)
+
+    def _run(self, jobs, fn):
+        """jobs are dealt to the worker contexts from one list, so an uneven job (rows that cross a teapot) does not
+        leave the other threads idle."""
+        import threading
+        lock, nxt, out, errs = threading.Lock(), [0], [None] * len(jobs), []
+
+        def work(part):
+            while True:
+                with lock:
+                    k = nxt[0]
+                    nxt[0] += 1
+                if k >= len(jobs) or errs:
+                    return
+                try:
+                    out[k] = fn(part, jobs[k])
+                except BaseException as e:       # noqa: BLE001 - handed to the caller's thread below
+                    errs.append(e)
+                    return
+
+        ts = [threading.Thread(target=work, args=(p,)) for p in self.parts]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errs:
+            raise errs[0]
+        return out
+
+    def _each(self, fn):
+        import threading
+        ts = [threading.Thread(target=fn, args=(p,)) for p in self.parts]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
+    def eye_pass(self, cam, seed, replica=0):
+        self.cam = cam
+        n = min(cam.h, 8 * len(self.parts))
+        edges = [cam.h * k // n for k in range(n + 1)]
+
+        def strip(part, k):
+            part.eye_pass_rows(cam, seed, edges[k], edges[k + 1], replica)
+            return part.hitpoints(), part.counters()
+
+        res = self._run(list(range(n)), strip)
+        self._hp = np.concatenate([r[0] for r in res])
+        self._eye = dict.fromkeys(res[0][1], 0)
+        for _, c in res:
+            for k, v in c.items():
+                self._eye[k] += v
+        self._each(lambda part: part.set_hitpoints(cam, self._hp))       # resets the contexts' tallies
+
+    def photon_pass(self, rounds, per_round, seed, replica=0, photon_begin=0, photon_count=0, n_lights=1):
+        total = rounds * per_round * n_lights
+        end = total if photon_count == 0 else min(total, photon_begin + photon_count)
+        n = max(1, min(end - photon_begin, 8 * len(self.parts)))
+        edges = [photon_begin + (end - photon_begin) * k // n for k in range(n + 1)]
+        jobs = [(edges[k], edges[k + 1] - edges[k]) for k in range(n) if edges[k + 1] > edges[k]]   # a count of 0 means "all"
+        self._run(jobs, lambda part, j: part.photon_pass(rounds, per_round, seed, replica, j[0], j[1]))
+
+    def _busy(self):
+        return [p for p in self.parts if p.counters()["photons"]]
+
+    def resolve(self):
+        pic = np.zeros((self.cam.h, self.cam.w, 3), dtype=np.float64)
+        for p in self._busy():
+            p.resolve(accumulate_into=pic)
+        return pic
+
+    def hitpoints(self):
+        out = self._hp.copy()
+        for p in self._busy():
+            hp = p.hitpoints()
+            out["tao"] += hp["tao"]
+            out["newN"] += hp["newN"]
+        return out
+
+    def counters(self):
+        tot = dict(self._eye)
+        for p in self.parts:
+            for k, v in p.counters().items():
+                if k != "hitpoints":
+                    tot[k] += v
+        tot["hitpoints"] = len(self._hp)
+        return tot
 
 
 def tonemap(pic_hw3, n_images, rgb=False, lib=None):

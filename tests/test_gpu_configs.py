@@ -31,8 +31,13 @@ def gpu():
     ctx.close()
 
 
-def _oracle(scene, newton_fp32=False):
-    o = ol.OracleContext(newton_fp32=newton_fp32)
+HOST_THREADS = min(16, os.cpu_count() or 1)      # a job's share of the GPU box's host cores
+
+
+def _oracle(scene, newton_fp32=False, threads=0):
+    """threads > 0: the serial oracle driven over that many host threads (ol.ParallelOracle: strips of rows, ranges of
+    photons, summed) for the sizes one thread does not finish in seconds."""
+    o = ol.ParallelOracle(threads, newton_fp32=newton_fp32) if threads else ol.OracleContext(newton_fp32=newton_fp32)
     o.set_scene(scene)
     return o
 
@@ -51,12 +56,20 @@ def _match(g, c):
 def _analytic_positions(g, c):
     """Plane / sphere HitPoints, fp64 on both sides.  Seen directly (tree node 0) they agree to 1e-9; behind a
     mirror or glass sphere the last-bit differences of the two arithmetics (FMA contraction on the GPU) are
-    magnified by the curved surface (distance / radius per bounce) and by the distance travelled: 1e-10
-    relative + 1e-7 absolute (measured worst case 4.5e-8 at z = 1482 behind the mirror ball).  Normals are the
-    same fp64 values stored as fp32: 1e-7 (measured 3e-8)."""
+    magnified by the curved surface (distance / radius per bounce) and by the distance travelled: 5e-10
+    relative + 1e-7 absolute (measured worst cases: 4.5e-8 at z = 1482 behind the mirror ball at 800 x 600; among the
+    405 414 such HitPoints of 1920 x 1080 one ray that leaves the mirror ball almost along the floor and meets it at
+    z = 64 822 is off by 2.3e-5 = 3.5e-10 relative, the next one by 1.1e-7).  Normals are the same fp64 values stored
+    as fp32: 1e-7 (measured 3e-8)."""
     direct = c["node"] == 0
+    err = np.abs(g["pos"] - c["pos"])
+    if (~direct).any():
+        rel = (err[~direct] / (1e-7 / 5e-10 + np.abs(c["pos"][~direct]))).max()
+        print(f"analytic HitPoints: {int(direct.sum())} direct, worst {err[direct].max() if direct.any() else 0:.2e}; "
+              f"{int((~direct).sum())} behind a mirror / glass, worst {err[~direct].max():.2e} "
+              f"({rel / 5e-10:.2f} of the tolerance), {(err[~direct].max(axis=1) > 1e-7).sum()} beyond 1e-7")
     assert np.allclose(g["pos"][direct], c["pos"][direct], rtol=1e-12, atol=1e-9)
-    assert np.allclose(g["pos"][~direct], c["pos"][~direct], rtol=1e-10, atol=1e-7)
+    assert np.allclose(g["pos"][~direct], c["pos"][~direct], rtol=5e-10, atol=1e-7)
     assert np.allclose(g["n"], c["n"], rtol=0, atol=1e-7)
 
 
@@ -88,21 +101,31 @@ def _bezier_hitpoints(g, c, first_bezier_obj, frac=0.99):
     assert np.median(nerr) <= 1e-5 and (nerr <= 1e-3).mean() >= 0.98 and nerr.max() <= 0.1
 
 
-def _run_pair(gpu, scene, cam, rounds, per_round, count, newton_fp32=False):
+def _run_pair(gpu, scene, cam, rounds, per_round, count, newton_fp32=False, threads=0):
     gpu.set_scene(scene)
     gpu.eye_pass(cam, SEED)
     gpu.photon_pass(rounds, per_round, SEED, photon_begin=0, photon_count=count)
-    o = _oracle(scene, newton_fp32)
+    o = _oracle(scene, newton_fp32, threads)
     o.eye_pass(cam, SEED)
     o.photon_pass(rounds, per_round, SEED, photon_begin=0, photon_count=count)
     return o
 
 
-def _bezier_case(gpu, scene, cam, rounds, per_round, count, first_bezier_obj=8):
+def _bezier_case(gpu, scene, cam, rounds, per_round, count, first_bezier_obj=8, threads=0, fp32_floor=False):
     """One Bezier scene through both passes against the fp32-Newton oracle (the stated tolerance) and the fp64 one (the
-    floor): HitPoints, tallies, image."""
+    floor): HitPoints, tallies, image.
+
+    fp32_floor: at 1920 x 1080 with 1 M photons a photon whose Newton solve on a teapot takes another iterate of the
+    same restart (Bezier.h:135-139 accepts every iterate within 0.01 of the surface) moves its later deposits, and each
+    deposit reaches about 75 HitPoints there, so a few hundred such photons are 19 000 pixels: the oracle's OWN two
+    arithmetics (Newton in float on the Bernstein form, and the reference's double) differ on 0.92 % of the pixels at
+    that size, more than the 0.5 % the tolerance allows, so the float oracle cannot define it there.  Then the image is
+    held to the stated tolerance against the double oracle, which is the reference's arithmetic (measured 99.74 %), and
+    against the float oracle it must be no farther off than the double oracle is (measured 19 150 against 19 051
+    outlier pixels)."""
+    images = {}
     for fp32 in (True, False):
-        o = _run_pair(gpu, scene, cam, rounds, per_round, count, newton_fp32=fp32)
+        o = _run_pair(gpu, scene, cam, rounds, per_round, count, newton_fp32=fp32, threads=threads)
         _bezier_hitpoints(gpu.hitpoints(), o.hitpoints(), first_bezier_obj)
         cg, co = gpu.counters(), o.counters()
         assert cg["photons"] == co["photons"]
@@ -110,8 +133,20 @@ def _bezier_case(gpu, scene, cam, rounds, per_round, count, first_bezier_obj=8):
             assert cg[k] == pytest.approx(co[k], rel=1e-3), k
         # nearest-box-first solves that skip boxes which cannot hold a nearer hit: fewer solves for the same hits
         assert 0.1 * co["newton_calls"] <= cg["newton_calls"] <= co["newton_calls"]
-        _image_parity(gpu.resolve(), o.resolve())
+        images[fp32] = (gpu.resolve(), o.resolve())
+        if not (fp32 and fp32_floor):
+            _image_parity(*images[fp32])
         o.close()
+    if fp32_floor:
+        (g, c32), (_, c64) = images[True], images[False]
+        mean = c32.mean()
+        d_gpu = np.abs(g - c32).max(axis=2) / mean
+        d_o64 = np.abs(c64 - c32).max(axis=2) / mean
+        print(f"against the float oracle: GPU {int((d_gpu > 1e-3).sum())} outlier pixels (within 1e-3: {(d_gpu <= 1e-3).mean():.5f}, "
+              f"MAE/mean {d_gpu.mean():.3g}), the double oracle {int((d_o64 > 1e-3).sum())} ({(d_o64 <= 1e-3).mean():.5f}, {d_o64.mean():.3g})")
+        assert (d_o64 <= 1e-3).mean() < 0.995          # else the plain assertion above is the one to use
+        assert (d_gpu > 1e-3).sum() <= 1.1 * (d_o64 > 1e-3).sum()
+        assert d_gpu.mean() <= 1e-4 and d_gpu.mean() <= 1.1 * d_o64.mean()
 
 
 def _gpu_properties(gpu, rounds, per_round, n_lights=1, halves=True):
@@ -217,6 +252,16 @@ def test_c4_quarter_size_against_oracle(gpu):
     _bezier_case(gpu, scenes.scene_teapot(4), scenes.default_camera(960, 540), 10000, 100, 100_000)
 
 
+def test_c4_full_size_against_oracle(gpu):
+    """The whole of config 4 — 1920 x 1080 = 2 073 600 pixels, four teapots = 128 patches, 1 M photons — against both
+    oracles, each driven over the host's threads (31 s of eye pass and 44 s of photon pass on one)."""
+    factory, (w, h), rounds, per_round = scenes.CONFIGS["c4_teapot4_1080p"]
+    assert (w, h, rounds * per_round) == (1920, 1080, 1_000_000)
+    scene = factory()
+    assert scene.patches.shape[0] == 128
+    _bezier_case(gpu, scene, scenes.default_camera(w, h), rounds, per_round, 0, threads=HOST_THREADS, fp32_floor=True)
+
+
 def test_c4_full_size_properties(gpu):
     factory, (w, h), rounds, per_round = scenes.CONFIGS["c4_teapot4_1080p"]
     gpu.set_scene(factory())
@@ -276,6 +321,31 @@ def test_c5_reduced_against_oracle(gpu):
     for k in ("segments", "deposits", "candidates", "accepted"):
         assert cg[k] == pytest.approx(co[k], rel=1e-3), k
     _image_parity(gpu.resolve(), o.resolve(), frac=0.995)
+
+
+def test_c5_full_size_against_oracle(gpu):
+    """The whole of config 5 — 1024 x 1024, all 50 M photons (48 batches on the GPU), the caustic under the glass ball —
+    against the oracle driven over the host's threads (two minutes on one).  No Bezier object: the oracle's Newton type
+    does not enter."""
+    factory, (w, h), rounds, per_round = scenes.CONFIGS["c5_caustic_1024"]
+    assert (w, h, rounds * per_round) == (1024, 1024, 50_000_000)
+    scene, cam = factory(), scenes.default_camera(w, h)
+    o = _run_pair(gpu, scene, cam, rounds, per_round, 0, threads=HOST_THREADS)
+    g, c = gpu.hitpoints(), o.hitpoints()
+    assert np.array_equal(np.sort(_key(g)), np.sort(_key(c)))
+    gm, cm, _ = _match(g, c)
+    _analytic_positions(gm, cm)
+    cg, co = gpu.counters(), o.counters()
+    assert cg["photons"] == co["photons"] == 50_000_000
+    for k in ("segments", "deposits", "candidates", "accepted"):
+        print(k, cg[k], co[k])
+        assert cg[k] == pytest.approx(co[k], rel=1e-6), k          # measured: equal, all 983 439 155 pairs
+    # per-HitPoint photon counts: the caustic's focus holds the largest ones
+    same = gm["newN"] == cm["newN"]
+    print(f"newN equal on {same.mean():.6f} of {len(cm)} HitPoints, largest {cm['newN'].max()}")
+    assert same.mean() >= 0.9999                                   # measured: every HitPoint
+    _image_parity(gpu.resolve(), o.resolve(), frac=0.995)
+    o.close()
 
 
 def test_c5_full_size_many_batches(gpu):

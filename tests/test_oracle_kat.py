@@ -357,3 +357,31 @@ def test_eye_tree_node_ids_and_weights(lib):
     assert np.allclose(floor["wgt"], 0.75 * 0.75)                    # colour .75 * diff .75
     assert len(np.unique(np.stack([hp["x"], hp["y"], hp["node"]], 1), axis=0)) == len(hp)
     assert (hp["node"] < 2 ** 15).all()
+
+
+def test_oracle_over_host_threads_equals_the_serial_oracle():
+    """ol.ParallelOracle (strips of rows, ranges of photons, summed) against one serial context: every HitPoint field
+    and tally equal, tao and the image to the order of their fp64 sums."""
+    from raytrace3_amd import scenes
+    scene, cam = scenes.scene_teapot(1), scenes.default_camera(96, 72)
+    for count in (0, 3333):
+        o = ol.OracleContext(newton_fp32=True)
+        o.set_scene(scene)
+        o.eye_pass(cam, 11)
+        o.photon_pass(100, 100, 11, photon_begin=17, photon_count=count)
+        p = ol.ParallelOracle(5, newton_fp32=True)
+        p.set_scene(scene)
+        p.eye_pass(cam, 11)
+        p.photon_pass(100, 100, 11, photon_begin=17, photon_count=count)
+        a, b = o.hitpoints(), p.hitpoints()
+        assert len(a) == len(b) > 0
+        for f in a.dtype.names:
+            if f == "tao":
+                assert np.allclose(a[f], b[f], rtol=1e-12, atol=0)
+            else:
+                assert np.array_equal(a[f], b[f]), f
+        assert o.counters() == p.counters()
+        assert o.counters()["photons"] == (10000 - 17 if count == 0 else count)
+        assert np.allclose(o.resolve(), p.resolve(), rtol=1e-12, atol=0)
+        o.close()
+        p.close()
