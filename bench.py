@@ -107,6 +107,20 @@ def _kernel(d, name):
     return {}
 
 
+KERNEL_SOURCES = ("raytrace3_amd/csrc/sppm_hip.hip", "raytrace3_amd/csrc/sppm_device.h")
+
+
+def kernel_source_sha256():
+    """sha256 over the kernel sources: tools/summarize_profile.py stamps a profile with it, and a bench line that takes its
+    counters from a profile made from other sources says so (`counters_stale`)."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def committed_profile(shared):
     """The newest committed rocprofv3 summary (profiles/*_pmc.json + *_kernel_stats.csv) of the launch mode asked for:
     several iterations in flight (the default command; its persistent grids are sized to share the GPU) or one.
@@ -160,6 +174,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("SPPM_INFLIGHT", "5")),
                     help="replica iterations in flight per GPU (one context = one HIP stream each)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every GPU traces the config's photons per step (the pass grows with N); strong: the config's photons "
+                         "are sharded over the N GPUs (config 3 as named: --config c3_teapot_800x600_10M --scaling strong --gpus 8)")
+    ap.add_argument("--steady-steps", type=int, default=200,
+                    help="iterations of a second timed region behind the first (value_steady): long enough for filling and draining "
+                         "the pipeline of iterations in flight not to weigh; 0 skips it")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
@@ -223,8 +243,11 @@ def main():
     for c in ctxs:
         c.set_scene(scene)
     n_lights = len(scene.light_list)
-    per_rank = rounds * per_round * n_lights
-    total_rounds = rounds * world
+    # weak: every rank brings the config's photons, the pass is world x as many; strong: the config's pass as it is,
+    # sharded (ranks' shares differ by one photon at most: distributed.photon_shard)
+    total_rounds = rounds * world if args.scaling == "weak" else rounds
+    photons_per_step = total_rounds * per_round * n_lights
+    per_rank = photons_per_step / world
     pics = [torch.zeros((h, w, 3), dtype=torch.float32, device="cuda") for _ in ctxs]
 
     def iteration(k, i):
@@ -248,17 +271,23 @@ def main():
     fence()
     for c in ctxs:
         c.stats_mode(True)      # counters and HIP-event spans accumulate over the timed steps: no per-step readback
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    for c in ctxs:
-        c.synchronize()         # waits for the library's stream and raises if a queued pass overflowed
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if via_host else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(first, n):
+        """n steps from step index `first` on, between two fences; the slowest rank's time."""
+        fence()
+        t0 = time.perf_counter()
+        for i in range(n):
+            step(first + i)
+        for c in ctxs:
+            c.synchronize()         # waits for the library's stream and raises if a queued pass overflowed
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if via_host else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    elapsed = timed(args.warmup, args.steps)
     # HIP-event durations measured on the library's stream(s) and tallies, summed over the timed steps
     tms, cnts = [c.timings() for c in ctxs], [c.counters() for c in ctxs]
     tm = {k: sum(t[k] for t in tms) for k in tms[0]}
@@ -279,11 +308,15 @@ def main():
         tm1, cn1, ds1, alone_steps = ctxs[0].timings(), ctxs[0].counters(), ctxs[0].device_stats(), ALONE_STEPS
     else:
         tm1, cn1, ds1, alone_steps = tm, counters, ctxs[0].device_stats(), args.steps
+    # A second, longer region: with five iterations in flight a region of `steps` iterations spends a good part of its
+    # time filling and draining that pipeline (at --steps 20 the whole region is 17 ms), which the driver's `value` contains
+    # by contract; the steady-state rate is reported beside it.
+    steady_s = timed(args.warmup + args.steps + ALONE_STEPS, args.steady_steps) if args.steady_steps > 0 else None
     alone = {k: tm1[k] / alone_steps for k in PHASES}
     gl, tl = max(1, tm1["gather_launches"]), max(1, tm1["trace_launches"] // 2)      # per step: one eye and one photon trace launch
 
     if rank == 0:
-        photons_total = per_rank * world * args.steps
+        photons_total = photons_per_step * args.steps
         pass_s = (alone["photon_trace_ms"] + alone["deposit_sort_ms"] + alone["gather_ms"]) / 1e3    # one photon pass, undisturbed
         how = ("HIP events on the library's stream" + (f", {ALONE_STEPS} iterations with one iteration in flight after the timed region (spans of "
                "the timed region include the other streams' kernels), launched as in the timed region: persistent grids sized to share "
@@ -291,6 +324,9 @@ def main():
         # the committed rocprofv3 counters are of the default workload: they say nothing about another configuration
         prof = committed_profile(len(ctxs) > 1) if (args.config == "c2_teapot_800x600" and rounds == cfg_rounds) else None
         pk, share, pname = prof if prof else ({}, {}, None)
+        cur_sha = kernel_source_sha256()
+        prof_sha = pk.get("_meta", {}).get("kernel_source_sha256") if pname else None
+        stale = None if not pname else (None if prof_sha is None else prof_sha != cur_sha)
         src = (f"profiles/{pname}: rocprofv3 --pmc passes of this command, per-launch averages; HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; "
                "kernels run one at a time under the profiler") if pname else None
 
@@ -300,7 +336,8 @@ def main():
         tv = valu_fields(tc, trace_s) if tc else None
         lane_cycles = tv.get("lane_cycles") if tv else None
         roofline = {
-            "kernel": "k_trace<MODE_PHOTON> (photon emission + PhotonTrace on persistent wavefronts; fp64 ray state, in-wave Bezier solves)",
+            "kernel": "k_trace_photon_bez (k_trace_photon_plain for a scene without Bezier objects): photon emission + PhotonTrace on persistent "
+                      "wavefronts; fp64 ray state, in-wave Bezier solves",
             "share_of_gpu_time": next((v for k, v in share.items() if k.startswith(TRACE_PHOTON)), None),
             "bound": "valu", "unit": "Tlane-cycle/s", "peak": PEAK_TLANE_CYCLES,
             "achieved": lane_cycles / trace_s / 1e12 if lane_cycles else None,
@@ -313,6 +350,9 @@ def main():
             "hbm_frac": (tc["hbm_traffic_bytes_per_launch"] / trace_s / 1e9 / HBM_PEAK_GBS) if tc and tc.get("hbm_traffic_bytes_per_launch") else None,
             "avg_launch_ms": trace_s * 1e3, "segments_per_launch": cn1["segments"] / tl,
             "counters_source": src, "measured": how,
+            "counters_stale": stale,
+            "counters_stale_is": "true: the kernel sources (sha256 over " + " + ".join(KERNEL_SOURCES) + ") are not the ones the committed counters were "
+                                 "collected from, only the durations are live; null: no committed counters in use, or a profile from before profiles were stamped",
         }
         # ---- the gather: what HBM sees of it against what it must move, and its vector-unit figures
         gather_s = alone["gather_ms"] * alone_steps / gl / 1e3
@@ -359,11 +399,17 @@ def main():
         out = {
             "metric": "Mphotons/s", "value": photons_total / elapsed / 1e6, "unit": "Mphotons/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "timed_region_ms": elapsed * 1e3,
+            "value_steady": photons_per_step * args.steady_steps / steady_s / 1e6 if steady_s else None,
+            "value_steady_is": (f"the same steps, {args.steady_steps} of them in a second region behind the timed one ({steady_s * 1e3:.0f} ms): filling and "
+                                f"draining the {len(ctxs)} iterations in flight no longer weighs") if steady_s else None,
+            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+            "kernel_source_sha256": cur_sha,
             "vs_baseline": None, "dtype": "f64 rays/gather + f32 Newton/flux", "data": "synthetic",
-            "config": {"inflight": len(ctxs), "workload": f"{args.config}: teapot.bpt Cornell scene {w}x{h}, {per_rank} photons/iter/GPU "
-                                   f"({rounds} rounds x {per_round}), one replica per step (own random streams, camera jittered by 0.00015 as "
-                                   f"Raytracer.h:434), photon-sharded over {world} GPU(s)",
+            "config": {"inflight": len(ctxs), "workload": f"{args.config}: {w}x{h}, {photons_per_step} photons per iteration "
+                                   f"({total_rounds} rounds x {per_round} x {n_lights} light(s)), {per_rank:.0f} per GPU, one replica per step (own random "
+                                   f"streams, camera jittered by 0.00015 as Raytracer.h:434), photon-sharded over {world} GPU(s), {args.scaling} scaling",
                        "hitpoints": counters["hitpoints"],
                        "collective": None if world == 1 else ("gloo over host copies (rehearsal: ranks share GPUs)" if via_host else "rccl all-reduce of the flux image")},
             "photon_pass_mphotons_per_s": per_rank / pass_s / 1e6 if pass_s > 0 else None,

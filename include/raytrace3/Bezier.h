@@ -1,12 +1,17 @@
 // Bezier.h — drop-in for the reference's raytracer/Bezier.h: AABBbox, Bezier3 (one bicubic
 // patch) and Bezier3Obj (a .bpt file of patches) with the reference's constructor
 // (raytracer/Bezier.h:199).  The patches are held as control points; the AABB culls and the
-// Newton ray-patch solve (Bezier.h:20-51, :112-159) run on the GPU.
+// Newton ray-patch solve (Bezier.h:20-51, :112-159) run on the GPU.  The members a host may call itself are here as
+// well: AABBbox::intersect and the Bernstein evaluators are a few lines of host arithmetic, Bezier3::newton / intersect
+// hand the solve to the GPU library.
 #pragma once
+#include <atomic>
 #include <fstream>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
+#include "Bridge.h"
 #include "Element.h"
 #include "Obj.h"
 #include "Vec3.h"
@@ -41,15 +46,116 @@ public:
         }
     }
     void clear() { pmin = MAX_VEC3; pmax = MIN_VEC3; }
+    // The reference's box test (raytracer/Bezier.h:20-51): a ray meets the box if, on some axis along which it moves
+    // (|dir| >= 1e-4 there), it reaches the face it approaches from outside (pmin going up, pmax going down) at a
+    // positive parameter, at a point that lies within the box's extent on the two other axes.  Only ENTRY faces are
+    // asked, so a ray that starts inside the box misses it.
+    bool intersect(const Vec3& org, const Vec3& dir) const {
+        for (int axis = 0; axis < 3; axis++) {
+            const double d = dir.val[axis];
+            if (IsZero(d)) continue;
+            const double face = d > 0 ? pmin.val[axis] : pmax.val[axis];
+            const double t = (face - org.val[axis]) / d;
+            if (!(t > 0)) continue;
+            const Vec3 at = org + t * dir;
+            bool within = true;
+            for (int other = 0; other < 3; other++)
+                if (other != axis && (at.val[other] > pmax.val[other] || at.val[other] < pmin.val[other])) within = false;
+            if (within) return true;
+        }
+        return false;
+    }
 };
 
 class Bezier3 {
+    // cubic Bernstein weights and their derivatives (raytracer/Bezier.h:71-74, :79-82)
+    static void weights(double t, double w[4]) {
+        const double s = 1 - t;
+        w[0] = s * s * s; w[1] = 3 * t * s * s; w[2] = 3 * t * t * s; w[3] = t * t * t;
+    }
+    static void weights_deriv(double t, double w[4]) {
+        const double s = 1 - t;
+        w[0] = -3 * s * s; w[1] = 3 * s * s - 6 * t * s; w[2] = 6 * t * s - 3 * t * t; w[3] = 3 * t * t;
+    }
+    static Vec3 blend(const Vec3& a, const Vec3& b, const Vec3& c, const Vec3& d, const double w[4]) {
+        return a * w[0] + b * w[1] + c * w[2] + d * w[3];
+    }
+
 public:
     Vec3 P[16];
     AABBbox aabb;
     void read(const Vec3 p[16]) {
         aabb.clear();
         for (int i = 0; i < 16; i++) { P[i] = p[i]; aabb.addpoint(P[i]); }
+    }
+
+    // One cubic Bezier curve and its derivative (raytracer/Bezier.h:69-84).
+    static Vec3 evalCurvePoint(const Vec3 P[4], double t) { double w[4]; weights(t, w); return blend(P[0], P[1], P[2], P[3], w); }
+    static Vec3 evalCurveDeriv(const Vec3 P[4], double t) { double w[4]; weights_deriv(t, w); return blend(P[0], P[1], P[2], P[3], w); }
+    // The patch S(u, v) and its partial derivatives (raytracer/Bezier.h:85-111): u runs along the four points of a row
+    // P[4 i .. 4 i + 3], v across the rows.  The order of evaluation is the reference's (rows in u first for S and S_v,
+    // columns in v first for S_u), so the values are the reference's to the last bit.
+    static Vec3 evalPatchPoint(const Vec3 P[16], double u, double v) {
+        double wu[4], wv[4];
+        weights(u, wu); weights(v, wv);
+        Vec3 row[4];
+        for (int i = 0; i < 4; i++) row[i] = blend(P[4 * i], P[4 * i + 1], P[4 * i + 2], P[4 * i + 3], wu);
+        return blend(row[0], row[1], row[2], row[3], wv);
+    }
+    static Vec3 evalPatchDerivU(const Vec3 P[16], double u, double v) {
+        double du[4], wv[4];
+        weights_deriv(u, du); weights(v, wv);
+        Vec3 col[4];
+        for (int i = 0; i < 4; i++) col[i] = blend(P[i], P[i + 4], P[i + 8], P[i + 12], wv);
+        return blend(col[0], col[1], col[2], col[3], du);
+    }
+    static Vec3 evalPatchDerivV(const Vec3 P[16], double u, double v) {
+        double wu[4], dv[4];
+        weights(u, wu); weights_deriv(v, dv);
+        Vec3 row[4];
+        for (int i = 0; i < 4; i++) row[i] = blend(P[4 * i], P[4 * i + 1], P[4 * i + 2], P[4 * i + 3], wu);
+        return blend(row[0], row[1], row[2], row[3], dv);
+    }
+
+    // Bezier3::newton (raytracer/Bezier.h:112-159): 5 maxIter restarts of maxIter Newton steps on (t, u, v), every iterate
+    // within 0.01 of the surface with u, v in [0, 1] a candidate, the candidate of smallest t returned, MAX_VEC3 if none.
+    // The solve runs on the GPU (sppm_debug_newton, on the context of slot 0, which is handed a scene of this one patch
+    // and gets the caller's scene back at its next pass).  The reference draws the restarts' starting points from its
+    // global generator, so two calls never use the same ones; here every call takes the counter-based streams of a call
+    // number of its own.  The GPU solver is built for the reference's MAX_ITER = 10, the only value the reference passes.
+    Vec3 newton(const Vec3& org, const Vec3& dir, int maxIter) const {
+        if (maxIter != MAX_ITER) throw std::invalid_argument("Bezier3::newton: the GPU solver runs MAX_ITER = 10 iterations of 50 restarts");
+        static std::atomic<uint32_t> calls{0};
+        const uint32_t call = calls.fetch_add(1);
+        sppm_object o;
+        std::memset(&o, 0, sizeof(o));
+        o.type = SPPM_OBJ_BEZIER; o.texture = -1; o.first_patch = 0; o.n_patches = 1;
+        for (int k = 0; k < 3; k++) { o.color[k] = 1; o.material.diff[k] = 0.75; }
+        o.material.refrn = 1.5; o.material.refln = 1;
+        double cp[48];
+        uint64_t tag = 0x62657a33ull;                        // not a tag Scene's flatten() could produce by chance: other salt, other length
+        for (int k = 0; k < 16; k++)
+            for (int c = 0; c < 3; c++) {
+                cp[3 * k + c] = P[k].val[c];
+                uint64_t bits;
+                std::memcpy(&bits, &cp[3 * k + c], 8);
+                tag = (tag ^ bits) * 1099511628211ull;
+            }
+        sppm_light light = {{0, 0, 0}, {1, 1, 1}};
+        sppm_scene sc;
+        std::memset(&sc, 0, sizeof(sc));
+        sc.n_objects = 1; sc.objects = &o; sc.n_patches = 1; sc.patches = cp; sc.n_lights = 1; sc.lights = &light;
+        sppm_host::Device& dev = sppm_host::Device::get(0);
+        std::lock_guard<std::mutex> g(dev.mu);
+        dev.use_scene(sc, tag | 1);
+        const int32_t patch = 0;
+        double tuv[3];
+        dev.check(sppm_debug_newton(dev.ctx, 1, org.val, dir.val, &patch, 0x6e6577746f6eull, call, tuv), "sppm_debug_newton");
+        return Vec3(tuv[0], tuv[1], tuv[2]);
+    }
+    // Bezier3::intersect (raytracer/Bezier.h:176-186): the solve only for a ray that meets the patch's box.
+    Vec3 intersect(const Vec3& org, const Vec3& dir) const {
+        return aabb.intersect(org, dir) ? newton(org, dir, MAX_ITER) : MAX_VEC3;
     }
 };
 

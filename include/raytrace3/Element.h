@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <string>
@@ -80,6 +81,25 @@ struct Texture {
     }
     Texture(int r, int c, const uint8_t* bgr) : rows(r), cols(c), texels(bgr, bgr + (size_t)r * c * 3) {}
 
+    // A hash of the size and the texels, by which the host bridge sees whether a GPU context's copy of the scene is still
+    // current.  It is computed once and kept while the texel array stays where it is and as large as it is (several
+    // million texels per stock texture, asked for once per pass or per RayTracer::ViewTrace call); a host that edits
+    // texels IN PLACE says so with touch().
+    uint64_t content_hash() const {
+        if (!(hash_valid_ && hashed_at_ == texels.data() && hashed_n_ == texels.size() && hashed_rows_ == rows && hashed_cols_ == cols)) {
+            uint64_t h = 1469598103934665603ull;
+            auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+            mix((uint64_t)rows); mix((uint64_t)cols);
+            const uint8_t* b = texels.data();
+            size_t i = 0, n = texels.size();
+            for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, b + i, 8); mix(w); }
+            for (; i < n; i++) mix(b[i]);
+            hash_ = h; hashed_at_ = texels.data(); hashed_n_ = n; hashed_rows_ = rows; hashed_cols_ = cols; hash_valid_ = true;
+        }
+        return hash_;
+    }
+    void touch() { hash_valid_ = false; }
+
     // Wrap-around bilinear lookup with the reference's index arithmetic (Element.h:61-72).
     Color colorUV(double u, double v) const {
         double row = (u - std::floor(u)) * rows, col = (v - std::floor(v)) * cols;
@@ -95,6 +115,11 @@ struct Texture {
     }
 
 private:
+    mutable uint64_t hash_ = 0;
+    mutable const uint8_t* hashed_at_ = nullptr;
+    mutable size_t hashed_n_ = 0;
+    mutable int hashed_rows_ = 0, hashed_cols_ = 0;
+    mutable bool hash_valid_ = false;
     Vec3 texel(int r, int c) const {
         const uint8_t* p = &texels[((size_t)r * cols + c) * 3];
         return Vec3(p[0] / 255.0, p[1] / 255.0, p[2] / 255.0);

@@ -69,6 +69,7 @@ struct Films {
         auto it = by_gpu.find(gpu);
         if (it != by_gpu.end()) return it->second;
         sppm_film* f = nullptr;
+        sppm_host::init();                 // before the first GPU call of the process, whichever comes first: a film or a context
         if (sppm_film_create(&f, gpu, w, h) != SPPM_OK) throw std::runtime_error("sppm_film_create failed on GPU " + std::to_string(gpu));
         by_gpu[gpu] = f;
         return f;

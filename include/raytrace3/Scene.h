@@ -1,6 +1,6 @@
 // Scene.h — drop-in for the reference's raytracer/Scene.h: Scene{objvec, plvec, init(),
-// NearCollide} (raytracer/Scene.h:93-183), plus the host bridge that flattens a scene into
-// the C-ABI structs of sppm_abi.h and keeps one GPU context per device.
+// NearCollide} (raytracer/Scene.h:93-183).  The host bridge that flattens a scene into the C-ABI structs of
+// sppm_abi.h is at the end of Obj.h, the GPU contexts it talks to in Bridge.h.
 #pragma once
 #include <cstdlib>
 #include <cstring>
@@ -16,148 +16,11 @@
 
 #include "../sppm_abi.h"
 #include "Bezier.h"
+#include "Bridge.h"
 #include "Element.h"
 #include "Light.h"
 #include "Obj.h"
 #include "Vec3.h"
-
-namespace sppm_host {
-
-struct FlatScene {
-    std::vector<sppm_object> objs;
-    std::vector<double> patches;
-    std::vector<sppm_texture> tex;
-    std::vector<sppm_light> lights;
-    sppm_scene c{};
-    uint64_t tag = 0;
-};
-
-// The tag decides whether a context's copy of the scene is still current (Device::ensure_scene).  The reference reads the
-// live objects on every ray, so a host may change a material, a colour, a position or a texture between two passes: the
-// tag therefore hashes the flattened CONTENT (every field of every object, the control points, the lights, each
-// texture's size and texels), not the addresses of the objects.
-inline void flatten(const std::vector<Obj*>& objvec, const std::vector<Light*>& plvec, FlatScene& f) {
-    f = FlatScene();
-    std::vector<const Texture*> seen;
-    uint64_t tag = 1469598103934665603ull;
-    auto mix = [&](uint64_t v) { tag = (tag ^ v) * 1099511628211ull; };
-    auto mix_bytes = [&](const void* p, size_t n) {
-        const unsigned char* b = (const unsigned char*)p;
-        size_t i = 0;
-        for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, b + i, 8); mix(w); }
-        for (; i < n; i++) mix(b[i]);
-    };
-    for (Obj* o : objvec) {
-        sppm_object so;
-        std::memset(&so, 0, sizeof(so));               // padding bytes, if a compiler adds any, hash alike
-        o->Describe(so, f.patches);
-        if (const Texture* t = o->getTexture()) {
-            size_t k = 0;
-            while (k < seen.size() && seen[k] != t) k++;
-            if (k == seen.size()) {
-                seen.push_back(t);
-                sppm_texture st;
-                st.rows = t->rows; st.cols = t->cols; st.texels = t->texels.data();
-                f.tex.push_back(st);
-                mix((uint64_t)t->rows); mix((uint64_t)t->cols);
-                mix_bytes(t->texels.data(), t->texels.size());
-            }
-            so.texture = (int)k;
-        }
-        f.objs.push_back(so);
-        mix_bytes(&so, sizeof(so));
-    }
-    mix_bytes(f.patches.data(), f.patches.size() * sizeof(double));
-    for (Light* l : plvec) {
-        sppm_light sl;
-        for (int k = 0; k < 3; k++) { sl.pos[k] = l->position().val[k]; sl.color[k] = l->power().val[k]; }
-        f.lights.push_back(sl);
-        mix_bytes(&sl, sizeof(sl));
-    }
-    mix(objvec.size()); mix(plvec.size());
-    f.tag = tag;
-    f.c.n_objects = (int)f.objs.size(); f.c.objects = f.objs.data();
-    f.c.n_patches = (int)(f.patches.size() / 48); f.c.patches = f.patches.data();
-    f.c.n_textures = (int)f.tex.size(); f.c.textures = f.tex.data();
-    f.c.n_lights = (int)f.lights.size(); f.c.lights = f.lights.data();
-}
-
-// A hardware queue per context: HIP's default of 4 queues per process folds the streams of four contexts and a film
-// onto shared queues, whose kernels then run one after the other (measured: 789 instead of 1015 Mphotons/s).  The HIP
-// runtime reads GPU_MAX_HW_QUEUES when it starts, so the value is set when the program is loaded, before any GPU call
-// (SPPM_HW_QUEUES picks another value, 0 leaves the environment alone).
-inline int set_hw_queues() {
-    const char* e = std::getenv("SPPM_HW_QUEUES");
-    const std::string v = (e && *e) ? e : "8";
-    return v == "0" ? 0 : setenv("GPU_MAX_HW_QUEUES", v.c_str(), 1);
-}
-inline const int hw_queues_set = set_hw_queues();
-
-// SPPM_DEVICES: comma-separated GPU ids, one context slot per entry (an id may repeat).
-inline std::vector<int> env_devices() {
-    std::vector<int> d;
-    const char* e = std::getenv("SPPM_DEVICES");
-    std::stringstream ss(e && *e ? e : "0,0,0,0");
-    std::string tok;
-    while (std::getline(ss, tok, ',')) if (!tok.empty()) d.push_back(std::atoi(tok.c_str()));
-    if (d.empty()) d.push_back(0);
-    return d;
-}
-
-// One library context per slot of SPPM_DEVICES, created on first use on that slot's GPU; `mu`
-// serialises callers because a context serves one host thread at a time.
-struct Device {
-    sppm_ctx* ctx = nullptr;
-    std::mutex mu;
-    uint64_t scene_tag = 0;
-    ~Device() { if (ctx) sppm_destroy(ctx); }
-    void check(int rc, const char* what) const {
-        if (rc != SPPM_OK) throw std::runtime_error(std::string(what) + " failed: " + (ctx ? sppm_last_error(ctx) : "no context"));
-    }
-    void ensure_scene(const std::vector<Obj*>& objvec, const std::vector<Light*>& plvec) {
-        FlatScene f;
-        flatten(objvec, plvec, f);
-        if (f.tag == scene_tag) return;
-        check(sppm_set_scene(ctx, &f.c), "sppm_set_scene");
-        scene_tag = f.tag;
-    }
-    static Device& get(int slot_index) {
-        static std::mutex reg_mu;
-        static std::map<int, std::unique_ptr<Device>> reg;
-        static const std::vector<int> devices = env_devices();
-
-        std::lock_guard<std::mutex> g(reg_mu);
-        const int key = (int)((size_t)(slot_index < 0 ? 0 : slot_index) % devices.size());
-        const int id = devices[(size_t)key];
-        auto& slot = reg[key];
-        if (!slot) {
-            slot.reset(new Device());
-            int rc = sppm_create(&slot->ctx, id);
-            if (rc != SPPM_OK) {
-                reg.erase(key);
-                throw std::runtime_error("sppm_create failed: no usable GPU " + std::to_string(id) + " (there is no CPU fallback)");
-            }
-        }
-        return *slot;
-    }
-};
-
-inline Collision intersect_objects(const std::vector<Obj*>& objs, const Ray& ray) {
-    static SpotLight dummy(Vec3(), Vec3(1, 1, 1));
-    std::vector<Light*> lights{&dummy};
-    Device& dev = Device::get(0);
-    std::lock_guard<std::mutex> g(dev.mu);
-    dev.ensure_scene(objs, lights);
-    sppm_collision c;
-    dev.check(sppm_debug_near_collide(dev.ctx, 1, ray.org.val, ray.dir.val, 0, 0, &c), "sppm_debug_near_collide");
-    if (c.obj < 0) return NoneColl;
-    Collision out(Vec3(c.pos[0], c.pos[1], c.pos[2]), ray.dir, c.dist, objs[c.obj], Vec3(c.n[0], c.n[1], c.n[2]),
-                  Vec3(c.color[0], c.color[1], c.color[2]));
-    out.inside = c.inside != 0;
-    return out;
-}
-
-}  // namespace sppm_host
 
 class Scene {
 public:

@@ -165,9 +165,12 @@ const char* sppm_last_error(const sppm_ctx* ctx);
  * Scene::NearCollide (raytracer/Scene.h:165-182); patch and object AABBs are
  * rebuilt as Bezier3::read / Bezier3Obj do (raytracer/Bezier.h:167-175, :226-231).
  * Waits for the passes still queued on the context.  Scene tables of up to
- * 64 KiB (240 B per object + 244 B per Bezier patch; the reference's scene: 9
- * objects, 32 patches, 10 KiB) are staged in LDS by the kernels, larger ones are
- * read from global memory.  Every patch is also cut into 4 x 4 sub-patches whose
+ * 64 KiB (296 B per object: a 264-B record and the 32 B the plane / sphere tests
+ * read, plus one spare such record; 244 B per Bezier patch; the reference's scene:
+ * 9 objects, 32 patches, 10 KiB) are staged in LDS by the kernels, larger ones are
+ * read from global memory (the photon kernel keeps 16.6 KiB more there — emission
+ * slices, sixteen lights, a sine table — and on a device whose workgroups have
+ * less than 80.6 KiB of LDS the staging area shrinks by what is missing).  Every patch is also cut into 4 x 4 sub-patches whose
  * boxes (384 B per patch) let the kernels skip solves that cannot find anything;
  * they ride in the staged tables while those stay within the 64 KiB (the
  * reference's scene: 22 KiB in all).  Capacity (SPPM_E_CAPACITY beyond it):

@@ -226,6 +226,8 @@ enum { MODE_EYE = 0, MODE_PHOTON = 1 };
 #define TRACE_SLOT_CHUNK 256u
 #endif
 #define TRACE_LDS_LIGHTS 16        // lights kept in LDS by the photon kernel (40 bytes each); more are read from global memory
+// what the photon kernel keeps in LDS beside the scene tables: 4 waves x 128 emission directions, the first lights, the sine table
+#define TRACE_PHOTON_LDS_EXTRA (4 * 128 * 3 * sizeof(double) + TRACE_LDS_LIGHTS * sizeof(DevLight) + 2 * SPPM_SINCOS_TAB * sizeof(double))
 #define DEP_HOLE 0x00ffffffu      // DepB::bucket of a claimed but unused slot (buckets are < 2^22)
 
 struct TraceParams {
@@ -1482,6 +1484,7 @@ struct sppm_ctx {
     bool have_scene = false;
     DevBuf<char> blob; int blob_bytes = 0, off_box = 0, off_cp = 0, off_pobj = 0, off_aobj = 0, off_sub = -1, n_objs = 0, n_patches = 0;
     bool scene_in_lds = true;             // the scene tables fit the LDS staging area (else: read from global memory)
+    size_t scene_lds_max = SCENE_LDS_MAX; // that area's size on this device (sppm_create)
     bool coop_only = false;               // more patches than a parked ray's patch mask can name: rays are never parked
     DevBuf<uchar4> texels;
     DevBuf<float> pw_q; DevBuf<double> pw_c;   // Newton tables (power basis around the patch centres)
@@ -1660,7 +1663,13 @@ int sppm_create(sppm_ctx** out, int device_id) {
     if (!ctx) return SPPM_E_NOMEM;
     ctx->device = device_id;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+        ctx->num_cu = prop.multiProcessorCount;
+        // the staging area for the scene tables: 64 KiB, or what a workgroup's LDS leaves beside the photon kernel's own
+        // slices (emission, lights, sine table) on a part with less than the 160 KiB of gfx950
+        const size_t group = prop.sharedMemPerBlock > 0 ? prop.sharedMemPerBlock : 64 * 1024;
+        ctx->scene_lds_max = group > TRACE_PHOTON_LDS_EXTRA ? std::min<size_t>(SCENE_LDS_MAX, group - TRACE_PHOTON_LDS_EXTRA) : 0;
+    }
     if (hipStreamCreate(&ctx->own_stream) != hipSuccess) {
         delete ctx;
         return SPPM_E_DEVICE;
@@ -1804,7 +1813,7 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
     int bytes = (off_aobj + (no + 1) * (int)sizeof(AObj) + 15) & ~15;   // one spare record: the plane / sphere loop looks one ahead
     // the sub-patch boxes ride in the blob (and so in LDS) where that keeps it within the staging area
     int off_sub = -1;
-    if (!sb.empty() && (size_t)bytes + sb.size() * sizeof(float) <= SCENE_LDS_MAX) { off_sub = bytes; bytes += (int)(sb.size() * sizeof(float)); }
+    if (!sb.empty() && (size_t)bytes + sb.size() * sizeof(float) <= ctx->scene_lds_max) { off_sub = bytes; bytes += (int)(sb.size() * sizeof(float)); }
     std::vector<char> blob((size_t)bytes, 0);
     if (off_sub >= 0) memcpy(blob.data() + off_sub, sb.data(), sb.size() * sizeof(float));
     else if (!sb.empty()) {
@@ -1950,7 +1959,7 @@ int sppm_set_scene(sppm_ctx* ctx, const sppm_scene* s) {
     ctx->blob_bytes = bytes; ctx->off_box = off_box; ctx->off_cp = off_cp; ctx->off_pobj = off_pobj; ctx->off_aobj = off_aobj; ctx->off_sub = off_sub; ctx->n_objs = no; ctx->n_patches = np;
     // Large scenes: tables beyond the LDS staging area are read from global memory, and with more patches than the patch
     // mask of a parked ray holds every Bezier solve happens in the tracing wave (the default anyway).
-    ctx->scene_in_lds = bytes <= SCENE_LDS_MAX;
+    ctx->scene_in_lds = (size_t)bytes <= ctx->scene_lds_max;
     ctx->coop_only = np > 64 * SPPM_MASK_WORDS || !ctx->scene_in_lds;
     std::vector<uchar4> tx(std::max<size_t>(1, total));
     for (int t = 0; t < s->n_textures; t++) {
@@ -2053,7 +2062,7 @@ static int close_chunks(sppm_ctx* ctx, Deposit* dep, RawHit* hits, uint64_t cap)
 template <int MODE>
 static void launch_trace(sppm_ctx* ctx, bool coop, int blocks, const SceneParams& sp, const TraceParams& tp) {
     // dynamic LDS: the scene tables, then (photon pass) 4 waves x 128 emission directions, the first lights and the sine table
-    const size_t lds = (ctx->scene_in_lds ? (((size_t)ctx->blob_bytes + 15) & ~(size_t)15) : 0) + (MODE == MODE_PHOTON ? 4 * 128 * 3 * sizeof(double) + TRACE_LDS_LIGHTS * sizeof(DevLight) + 2 * SPPM_SINCOS_TAB * sizeof(double) : 0);
+    const size_t lds = (ctx->scene_in_lds ? (((size_t)ctx->blob_bytes + 15) & ~(size_t)15) : 0) + (MODE == MODE_PHOTON ? TRACE_PHOTON_LDS_EXTRA : 0);
     if (!ctx->scene_in_lds) hipLaunchKernelGGL((k_trace<MODE, true, false>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);   // coop_only
     else if (coop && sp.n_patches == 0 && MODE == MODE_PHOTON) hipLaunchKernelGGL(k_trace_photon_plain, dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
     else if (coop && sp.n_patches == 0) hipLaunchKernelGGL((k_trace<MODE, true, true, false>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
@@ -2126,6 +2135,17 @@ static int overflow_code(sppm_ctx* ctx, const DevCounters& dc, bool can_retry_qu
     return SPPM_RETRY_HITS;   // HitPoint buffer too small: the eye pass retries with more room
 }
 
+// Records the ray queues of run_trace must hold.  With in-wave solves nothing is parked for a solve: only the refraction
+// branches of eye paths through a material that both reflects and refracts are queued (as fresh rays), at most one per
+// path vertex, and their queue grows by doubling when a pass overflows it (park_scale).  Parked solves (the non-default
+// modes) can queue every work item.  Seed rays (n_seed) are records of the queue themselves.
+static uint64_t trace_park_cap(const sppm_ctx* ctx, int mode, bool first_coop, bool has_dual_lobe, uint64_t fresh_count, uint64_t n_seed) {
+    const bool branches = mode == MODE_EYE && has_dual_lobe;
+    return std::max<uint64_t>(n_seed, !first_coop ? std::max<uint64_t>(fresh_count, 1u << 16)
+                                      : branches  ? std::max<uint64_t>(std::max(fresh_count, n_seed) / 4, ctx->branch_queue_min) * ctx->park_scale
+                                                  : (1u << 12));
+}
+
 // Traces one set of fresh work items (pixels or photons) to completion.  The control block must have
 // been reset.  The launches are queued without looking at their results wherever the schedule is known
 // in advance:
@@ -2146,18 +2166,17 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
     // waves, which would serialise 64 solves each while the other waves idle: then they are parked and
     // solved by k_newton (SPPM_EYE_SCATTER=0, or SPPM_PHOTON_COOP=0 for photons).
     const bool first_coop = n_seed > 0 || ctx->force_coop || ctx->coop_only || (mode == MODE_PHOTON && ctx->photon_coop) || (mode == MODE_EYE && ctx->eye_scatter);
-    // The ray and task queues are sized by what can reach them.  With in-wave solves nothing is parked for a solve: only
-    // the refraction branches of eye paths through a material that both reflects and refracts are queued (as fresh rays),
-    // at most one per path vertex, and their queue grows by doubling when a pass overflows it (park_scale; the eye pass
-    // retries like it does for the HitPoint buffer).  Parked solves (the non-default modes) can queue every work item
-    // with up to 16 patch tasks each.
-    const bool branches = mode == MODE_EYE && has_dual_lobe;
-    const uint64_t park_cap = std::max<uint64_t>(n_seed, !first_coop ? std::max<uint64_t>(fresh_count, 1u << 16)
-                                                         : branches  ? std::max<uint64_t>(std::max(fresh_count, n_seed) / 4, ctx->branch_queue_min) * ctx->park_scale
-                                                                     : (1u << 12));
+    // The ray and task queues are sized by what can reach them (trace_park_cap; the eye pass retries with a doubled
+    // park_scale like it does for the HitPoint buffer); parked solves bring up to 16 patch tasks per ray.
+    const uint64_t park_cap = trace_park_cap(ctx, mode, first_coop, has_dual_lobe, fresh_count, n_seed);
     const uint64_t task_cap = first_coop ? 16 : 16 * park_cap;
     if (task_cap > 0xffffffffull) return fail(ctx, SPPM_E_CAPACITY, "too many work items for one round");
+    // Seed rays already sit in queue 1 (upload_seed_rays sized it with trace_park_cap too): growing the queue here would
+    // free them, since DevBuf::reserve does not keep a buffer's contents.
+    if (n_seed > 0 && ctx->park[1].n < park_cap) return fail(ctx, SPPM_E_DEVICE, "seed queue smaller than the trace rounds need");
+    const ParkRec* const seeds_at = ctx->park[1].p;
     HIPCHK(ctx->park[0].reserve(park_cap)); HIPCHK(ctx->park[1].reserve(park_cap));
+    if (n_seed > 0 && ctx->park[1].p != seeds_at) return fail(ctx, SPPM_E_DEVICE, "seed queue moved after the upload");
     HIPCHK(ctx->ntask[0].reserve(task_cap)); HIPCHK(ctx->ntask[1].reserve(task_cap));
     HIPCHK(ctx->nres.reserve(task_cap));
     unsigned long long* sc = ctx->scalars();
@@ -2216,7 +2235,7 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
     for (int round = 0; round < 256; round++) {
         if (int rc = read_queues(ctx, q)) return rc;
         *synced = true;
-        if (int rc = overflow_code(ctx, q.dc, first_coop)) return rc;
+        if (int rc = overflow_code(ctx, q.dc, first_coop || mode == MODE_PHOTON)) return rc;    // photons: the caller retries a full deposit buffer
         const unsigned long long n_park = q.sc[cur ? SC_PARK1 : SC_PARK0], n_tasks = q.sc[cur ? SC_TASK1 : SC_TASK0];
         if (ctx->verbose) fprintf(stderr, "[sppm] mode %d round %d: %llu rays queued, %llu newton tasks\n", mode, round, n_park, n_tasks);
         if (n_park == 0) return SPPM_OK;
@@ -2302,7 +2321,7 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
         int rc = run_trace(ctx, MODE_EYE, tp, 0, npx, ctx->has_dual_lobe, true, q, &synced);
         toc(ctx);
         if (rc == SPPM_OK) break;
-        if (rc != SPPM_RETRY_HITS && rc != SPPM_RETRY_PARK) return rc;
+        if (rc != SPPM_RETRY_HITS && rc != SPPM_RETRY_PARK) return rc < 0 ? rc : fail(ctx, SPPM_E_CAPACITY, "a queue the eye pass does not use reported an overflow");
         if (attempt == 7) return fail(ctx, SPPM_E_CAPACITY, "HitPoint buffer or branch queue overflowed after 7 capacity doublings");
         if (rc == SPPM_RETRY_HITS) hit_cap *= 2; else ctx->park_scale *= 2;
         if (!ctx->accumulate_stats) drop_spans(ctx);
@@ -2451,7 +2470,10 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
     // reference's open tunnel leaves 3.7 diffuse hits per photon, of which 1.9 are stored).  A counting-sorted batch that
     // overflows them is traced again with more (below); a placed batch only uses this buffer as its overflow list.
     auto cap_for = [&](double per_photon) { return (uint64_t)std::ceil((double)batch * std::min<double>(per_photon, SPPM_MAX_DEP + 1)) + dep_slack(ctx, batch); };
-    uint64_t dep_cap = cap_for(ctx->dep_per_photon);
+    // With the radius update on every batch is counting-sorted and batches are a few rounds: they get the worst-case room
+    // while that stays under 256 MiB, so that no batch has to be looked at before the next one is queued.
+    const bool worst_case_room = sweeps && batch * (SPPM_MAX_DEP + 1) * sizeof(Deposit) <= (256ull << 20);
+    uint64_t dep_cap = cap_for(worst_case_room ? SPPM_MAX_DEP + 1 : ctx->dep_per_photon);
     // The buffer of deposits as traced is reserved batch by batch: a counting-sorted batch needs dep_cap slots of it, a
     // placed one only an overflow list.
     const uint64_t over_room = std::max<uint64_t>(1u << 16, batch / 4);
@@ -2479,27 +2501,43 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
             tp.over = ctx->dep.p; tp.n_over = ctx->scalars() + SC_OVER; tp.over_cap = over_cap;
             tic(ctx, PH_TRACE);
             bool synced = false;
-            if (int rc = run_trace(ctx, MODE_PHOTON, tp, first, count, false, false, q, &synced)) return rc;
+            if (int rc = run_trace(ctx, MODE_PHOTON, tp, first, count, false, false, q, &synced)) {
+                if (rc < 0) return rc;
+                ctx->place_valid = false;          // parked-solve rounds saw the overflow list full: the next batch lays the room out anew
+                return fail(ctx, SPPM_E_CAPACITY, "the overflow list of a placed photon batch is full");
+            }
             toc(ctx);
         } else {
             HIPCHK(ctx->dep.reserve(dep_cap));
             fill_photon_params(ctx, tp, per_round, dep_cap, seed, replica, ctx->counters.p);
             lay_out = ctx->place_enabled && ctx->dep_filter && !sweeps && ctx->n_hp > 0 && count == batch;
             tp.dcount_all = lay_out ? ctx->dcount_all() : nullptr;
-            DevCounters first_failed{};
+            DevCounters first_failed{}, before{};
+            // Parked-solve rounds (SPPM_PHOTON_COOP=0) stop at the round that sees the buffer full, so the failed attempt's
+            // tallies are partial: that mode, which waits for the stream every round anyway, notes the tallies before the batch.
+            const bool rounds_on_host = !(ctx->force_coop || ctx->coop_only || ctx->photon_coop);
+            if (rounds_on_host) { if (int rc = read_queues(ctx, q)) return rc; before = q.dc; }
+            bool tallies_restored = false;
             for (int attempt = 0;; attempt++) {
                 if (int rc = launch_pass_reset(ctx, false, ctx->cursor(), (lay_out ? 3 : 2) * ((size_t)M + 1))) return rc;   // + cursor, dcount (and dcount_all)
                 tic(ctx, PH_TRACE);
                 bool synced = false;
-                if (int rc = run_trace(ctx, MODE_PHOTON, tp, first, count, false, false, q, &synced)) return rc;
+                const int trc = run_trace(ctx, MODE_PHOTON, tp, first, count, false, false, q, &synced);
                 toc(ctx);
+                if (trc < 0) return trc;
                 // A counting-sorted batch is where the deposit buffer can overflow with the host still at hand to trace it
                 // again: one look at the flags before the deposits are sorted and gathered (placed batches, the steady
-                // state, have no such wait).
-                if (int rc = read_queues(ctx, q)) return rc;
-                const int oc = overflow_code(ctx, q.dc, true);
+                // state, have no such wait; nor has a batch whose buffer holds the 14 deposits a path can leave — every
+                // batch of a pass with the radius update on — which goes on asynchronously like them).
+                int oc = trc;              // parked-solve rounds look at the flags themselves and hand a full buffer back here
+                bool partial = trc != SPPM_OK;
+                if (trc == SPPM_OK) {
+                    if (attempt == 0 && dep_cap >= cap_for(SPPM_MAX_DEP + 1)) break;
+                    if (int rc = read_queues(ctx, q)) return rc;
+                    oc = overflow_code(ctx, q.dc, true);
+                }
                 if (oc == SPPM_OK) {
-                    if (attempt > 0) {
+                    if (attempt > 0 && !tallies_restored) {
                         // the photons of the failed attempts were tallied as well: back to the tallies after the first of them
                         // (the stream is idle: read_queues waited for it)
                         DevCounters fix = q.dc;
@@ -2511,8 +2549,12 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
                 }
                 if (oc != SPPM_RETRY_DEP || attempt == 3) return oc < 0 ? oc : fail(ctx, SPPM_E_CAPACITY, "a ray / deposit queue overflowed");
                 if (attempt == 0) first_failed = q.dc;
+                if (partial) {             // the stream is idle: the rounds waited for it
+                    HIPCHK(hipMemcpy(ctx->counters.p, &before, offsetof(DevCounters, overflow), hipMemcpyHostToDevice));
+                    tallies_restored = true;
+                }
                 // the slot counter ran on past the capacity: it says what the batch needs
-                const double need = (double)q.sc[SC_DEP] / (double)count;
+                const double need = partial ? SPPM_MAX_DEP + 1 : (double)q.sc[SC_DEP] / (double)count;      // rounds cut short say nothing
                 ctx->dep_per_photon = std::min<double>(SPPM_MAX_DEP + 1, std::max(2.0 * ctx->dep_per_photon, need * 1.25));
                 dep_cap = cap_for(ctx->dep_per_photon);
                 if (ctx->verbose) fprintf(stderr, "[sppm] deposit buffer overflowed (%.2f slots per photon needed): retrying with %.2f\n", need, ctx->dep_per_photon);
@@ -2753,21 +2795,29 @@ int sppm_near_collide_noalloc(sppm_ctx* ctx, uint64_t n, const double* org, cons
     HIPCHK(hipSetDevice(ctx->device));
     std::lock_guard<std::mutex> turn(g_scratch_mu[ctx->device]);     // the GPU's one array serves one call at a time
     NoAllocScratch* s = (NoAllocScratch*)g_scratch_ptr[ctx->device];
-    HIPCHK(hipMemcpyAsync(s->org, org, 3 * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(s->dir, dir, 3 * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    if (int rc = launch_fill(ctx, (uint32_t*)&s->counters, sizeof(DevCounters) / 4, 0u)) return rc;
-    const uint32_t rng = host_rng_base(seed, replica * 4u + D_EYE);
-    if (ctx->scene_in_lds)
-        hipLaunchKernelGGL(k_debug_near_collide<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)ctx->blob_bytes, ctx->stream,
-                           ctx->scene_params(), (uint32_t)n, (const double*)s->org, (const double*)s->dir, rng, s->out, &s->counters);
-    else
-        hipLaunchKernelGGL(k_debug_near_collide<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                           ctx->scene_params(), (uint32_t)n, (const double*)s->org, (const double*)s->dir, rng, s->out, &s->counters);
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_add_newton_calls, dim3(1), dim3(64), 0, ctx->stream, ctx->counters.p, (const DevCounters*)&s->counters);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out, s->out, n * sizeof(sppm_collision), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // Work that was queued before a failing step may still read or write the array: the turn is only given up (the guard
+    // above, on return) once the stream is idle, whatever the outcome.
+    auto run = [&]() -> int {
+        HIPCHK(hipMemcpyAsync(s->org, org, 3 * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(s->dir, dir, 3 * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        if (int rc = launch_fill(ctx, (uint32_t*)&s->counters, sizeof(DevCounters) / 4, 0u)) return rc;
+        const uint32_t rng = host_rng_base(seed, replica * 4u + D_EYE);
+        if (ctx->scene_in_lds)
+            hipLaunchKernelGGL(k_debug_near_collide<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)ctx->blob_bytes, ctx->stream,
+                               ctx->scene_params(), (uint32_t)n, (const double*)s->org, (const double*)s->dir, rng, s->out, &s->counters);
+        else
+            hipLaunchKernelGGL(k_debug_near_collide<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->scene_params(), (uint32_t)n, (const double*)s->org, (const double*)s->dir, rng, s->out, &s->counters);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_add_newton_calls, dim3(1), dim3(64), 0, ctx->stream, ctx->counters.p, (const DevCounters*)&s->counters);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out, s->out, n * sizeof(sppm_collision), hipMemcpyDeviceToHost, ctx->stream));
+        return SPPM_OK;
+    };
+    const int rc = run();
+    const hipError_t idle = hipStreamSynchronize(ctx->stream);
+    if (rc != SPPM_OK) return rc;
+    if (idle != hipSuccess) return fail(ctx, SPPM_E_DEVICE, hipGetErrorString(idle));
     return SPPM_OK;
 }
 
@@ -2834,7 +2884,8 @@ int sppm_debug_photon_deposits(sppm_ctx* ctx, uint64_t rounds, uint32_t per_roun
 }
 
 // Ray records of the caller's making, uploaded as the seed queue of run_trace (queue 1).
-static int upload_seed_rays(sppm_ctx* ctx, uint64_t n, const double* org, const double* dir, const int32_t* dep, const double* carry, const uint32_t* id) {
+// Both queues are brought to the size the trace rounds will ask for BEFORE the copy: run_trace must find nothing to grow.
+static int upload_seed_rays(sppm_ctx* ctx, int mode, uint64_t n, const double* org, const double* dir, const int32_t* dep, const double* carry, const uint32_t* id) {
     std::vector<ParkRec> recs((size_t)n);
     for (uint64_t i = 0; i < n; i++) {
         ParkRec& r = recs[(size_t)i];
@@ -2842,7 +2893,8 @@ static int upload_seed_rays(sppm_ctx* ctx, uint64_t n, const double* org, const 
         for (int k = 0; k < 3; k++) { r.o[k] = org[3 * i + k]; r.d[k] = dir[3 * i + k]; r.carry[k] = (float)carry[3 * i + k]; }
         r.id = id[i]; r.dep = dep ? dep[i] : 0; r.node = 0; r.aobj = -1;
     }
-    HIPCHK(ctx->park[1].reserve(std::max<uint64_t>(n, 1u << 12)));
+    const uint64_t cap = trace_park_cap(ctx, mode, true, mode == MODE_EYE && ctx->has_dual_lobe, 0, n);
+    HIPCHK(ctx->park[0].reserve(cap)); HIPCHK(ctx->park[1].reserve(cap));
     HIPCHK(hipMemcpyAsync(ctx->park[1].p, recs.data(), (size_t)n * sizeof(ParkRec), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));     // recs goes out of scope
     return SPPM_OK;
@@ -2860,7 +2912,7 @@ int sppm_view_trace(sppm_ctx* ctx, uint64_t n, const double* org, const double* 
     HIPCHK(hipSetDevice(ctx->device));
     if (int rc = check_deferred(ctx)) return rc;
     if (ctx->have_eye) if (int rc = ensure_meta(ctx)) return rc;     // the raw array is about to be reused
-    if (int rc = upload_seed_rays(ctx, n, org, dir, dep, wgt, pixel)) return rc;
+    if (int rc = upload_seed_rays(ctx, MODE_EYE, n, org, dir, dep, wgt, pixel)) return rc;
     // the HitPoints land in the raw array of the eye pass (free between passes); their histogram goes to a throw-away table
     uint64_t hit_cap = (SPPM_MAX_DEP + 1) * n + dep_slack(ctx, n);
     DevBuf<uint32_t> sink; DevBuf<DevCounters> tallies;
@@ -2920,7 +2972,7 @@ int sppm_photon_trace(sppm_ctx* ctx, uint64_t n, const double* org, const double
     for (uint64_t i = 0; i < n; i++) if (dep && (dep[i] < 0 || dep[i] > SPPM_MAX_DEP + 1)) return fail(ctx, SPPM_E_INVALID, "depth out of range");
     HIPCHK(hipSetDevice(ctx->device));
     if (int rc = check_deferred(ctx)) return rc;
-    if (int rc = upload_seed_rays(ctx, n, org, dir, dep, flux, id)) return rc;
+    if (int rc = upload_seed_rays(ctx, MODE_PHOTON, n, org, dir, dep, flux, id)) return rc;
     const uint32_t M = ctx->grid.mask + 1;
     const uint64_t dep_cap = (SPPM_MAX_DEP + 1) * n + dep_slack(ctx, n);
     HIPCHK(ctx->dep.reserve(dep_cap)); HIPCHK(ctx->sdep.reserve(std::max<uint64_t>(dep_cap, ctx->place_valid ? ctx->place_total : 0)));

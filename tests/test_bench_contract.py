@@ -60,6 +60,14 @@ def test_bench_line_keeps_the_contract():
         assert c["all_cores"]["cores"] > 4 and c["all_cores"]["value"] > 0
     t = c["all_cores_grid_gather_no_update_sweep"]     # the restatement without the reference's dead sweep: the fairer CPU figure
     assert t["value"] > 0 and t["cores"] >= 1 and "no per-round update() sweep" in t["sample"]
+    # the timed region's length, a second longer region beside it, the hardware queues the run had, and whether the committed
+    # counters were collected from the kernel sources that ran
+    assert d["timed_region_ms"] == pytest.approx(d["ms_per_step"] * d["steps"])
+    assert d["value_steady"] > 10 and "200" in d["value_steady_is"]
+    assert d["hw_queues"] == "8"
+    assert len(d["kernel_source_sha256"]) == 64 and r["counters_stale"] in (True, False, None)
+    if r["achieved"] is None:
+        assert r["counters_stale"] is None
     k = d["kernel_ms_per_step_one_in_flight"]
     assert all(k[x] >= 0 for x in ("eye_trace_ms", "grid_build_ms", "photon_trace_ms", "deposit_sort_ms", "gather_ms", "resolve_ms"))
     assert d["counters_per_step"]["photons"] == 1_000_000
@@ -75,6 +83,18 @@ def test_bench_starts_its_own_ranks():
     assert d["counters_per_step"]["photons"] == 1_000_000          # per rank: the pass of a step is 2 M photons, sharded
     assert "gloo" in d["config"]["collective"]
     assert d["value"] == pytest.approx(2e6 / (d["ms_per_step"] / 1e3) / 1e6, rel=1e-6)
+
+
+@pytest.mark.gpu
+def test_bench_strong_scaling_shards_the_configs_own_pass():
+    """--scaling strong: the pass is the config's (here 3 000 rounds x 100 photons of config 2's scene), sharded over the ranks,
+    where weak scaling gives every rank that many."""
+    d = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--inflight", "2", "--no-cpu-baseline", "--scaling", "strong", "--rounds", "3000",
+               "--steady-steps", "0", env={"SPPM_BENCH_SHARE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value_steady"] is None
+    assert d["counters_per_step"]["photons"] == 150_000            # per rank: half of the 300 000-photon pass
+    assert "300000 photons per iteration" in d["config"]["workload"]
+    assert d["value"] == pytest.approx(3e5 / (d["ms_per_step"] / 1e3) / 1e6, rel=1e-6)
 
 
 def test_bench_refuses_a_launcher_of_another_size():

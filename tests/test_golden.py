@@ -85,10 +85,13 @@ def test_gpu_matches_golden_newton(gpu):
     r = gpu.newton(g["org"], g["dir"], g["patch"], int(g["seed"]))
     ref = g["tuv_fp64"]
     found_r, found_c = r[:, 0] < 1e19, ref[:, 0] < 1e19
-    assert (found_r != found_c).sum() <= 3
+    assert (found_r != found_c).sum() <= 1                                   # measured: none
     both = found_r & found_c
     err = np.abs(r[both] - ref[both]).max(axis=1)
-    assert np.median(err) < 1e-4 and (err < 1e-3).mean() > 0.9 and err.max() < 0.05
+    print(f"golden newton: {int((found_r != found_c).sum())} decision flips, median {np.median(err):.2e}, within 1e-3 {(err < 1e-3).mean():.4f}, max {err.max():.2e}")
+    # measured: median 4.0e-6, 5 of 240 beyond 1e-3 (another iterate of the same restart passed the residual test first), worst
+    # 0.0124; the residual rule of Bezier.h:135 lets candidates lie 0.01 from the surface, so nothing can be 0.02 apart
+    assert np.median(err) < 1e-5 and (err < 1e-3).mean() >= 0.958 and err.max() < 0.02
 
 
 @pytest.mark.gpu
@@ -105,9 +108,10 @@ def test_gpu_matches_golden_photon_deposits(gpu):
     kg = gold[:, 0].astype(np.int64) * 16 + gold[:, 1].astype(np.int64)
     common, i, j = np.intersect1d(kd, kg, return_indices=True)
     # a path that touches the teapot can differ at the Newton residual scale and then diverge
-    assert len(common) >= 0.95 * len(kg), (len(common), len(kg))
+    assert len(common) >= 0.99 * len(kg), (len(common), len(kg))              # measured: all 715
     perr = np.abs(dep[i, 2:5] - gold[j, 2:5]).max(axis=1)
-    assert (perr < 1e-6).mean() >= 0.9, (perr < 1e-6).mean()
+    print(f"golden deposits: {len(common)} of {len(kg)} common ({len(common) / len(kg):.4f}), within 1e-6 {(perr < 1e-6).mean():.4f}")
+    assert (perr < 1e-6).mean() >= 0.986, (perr < 1e-6).mean()                # measured: 710 of 715
     ok = perr < 1e-6
     assert np.allclose(dep[i][ok, 5:8], gold[j][ok, 5:8], rtol=0, atol=1e-5)     # normals (stored fp32)
     assert np.allclose(dep[i][ok, 8:11], gold[j][ok, 8:11], rtol=2e-5, atol=0)   # flux (fp32 products)

@@ -281,8 +281,8 @@ def _room_with_teapots(extra):
 
 @pytest.mark.parametrize("extra", [3, 6])
 def test_large_scenes(gpu, extra):
-    """Seven teapots = 224 patches: the staged scene tables take 58 KiB of LDS and the photon kernel adds 12 KiB of
-    emission slices, the largest workgroup footprint there is.  Ten teapots = 320 patches: the tables (82 KiB) no longer
+    """Seven teapots = 224 patches: the staged scene tables take 58 KiB of LDS and the photon kernel adds 16.6 KiB
+    (emission slices, sixteen lights, the sine table of the diffuse bounce), the largest workgroup footprint there is.  Ten teapots = 320 patches: the tables (82 KiB) no longer
     fit the staging area and are read from global memory, and rays are never parked (a parked ray names its patches in
     a 256-bit mask).  Both passes against both oracles, at the stated tolerances."""
     scene, cam = _room_with_teapots(extra), scenes.default_camera(240, 135)
@@ -378,11 +378,13 @@ def test_batch_size_is_immaterial(gpu):
     small.close()
 
 
-def test_queues_sized_for_the_usual_case_grow_when_a_pass_needs_more(gpu, monkeypatch):
+@pytest.mark.parametrize("photon_coop", ["1", "0"])
+def test_queues_sized_for_the_usual_case_grow_when_a_pass_needs_more(gpu, monkeypatch, photon_coop):
     """Deposit slots are provided per photon for what the reference's scene needs (4, against the 14 a path could leave), the
     eye pass's branch queue for a quarter of the pixels: a counting-sorted photon batch that overflows its deposit buffer
     and an eye pass that overflows its branch queue are run again with more room, and give the pass a context with
-    ample room gives — HitPoints, per-HitPoint photon counts and every tally (the failed attempts are not counted twice)."""
+    ample room gives — HitPoints, per-HitPoint photon counts and every tally (the failed attempts are not counted twice).
+    photon_coop = "0": the photons' Bezier solves go through parked rounds, whose host loop sees the full buffer itself."""
     scene, cam = _materials_scene(), scenes.default_camera(96, 72)        # two-lobe glass: the eye paths branch
     gpu.set_scene(scene)
     want = []
@@ -394,6 +396,7 @@ def test_queues_sized_for_the_usual_case_grow_when_a_pass_needs_more(gpu, monkey
     monkeypatch.setenv("SPPM_DEP_PER_PHOTON", "0.05")        # 20 000 slots (+ the waves' open chunks) for over a million deposits
     monkeypatch.setenv("SPPM_BRANCH_QUEUE_MIN", "32")
     monkeypatch.setenv("SPPM_PLACE", "0")                     # every batch counting-sorted
+    monkeypatch.setenv("SPPM_PHOTON_COOP", photon_coop)
     tight = SppmContext(0)
     try:
         tight.set_scene(scene)

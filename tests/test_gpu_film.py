@@ -51,13 +51,15 @@ def test_film_sums_replicas_like_the_host_loop():
         assert np.allclose(got, host_sum, rtol=1e-5, atol=1e-7 * host_sum.mean())
         # against the oracle: the flux-image tolerance of the parity tests (relative to the image mean)
         d = np.abs(got - oracle_sum).max(axis=2) / oracle_sum.mean()
-        assert (d <= 1e-3).mean() >= 0.97
+        print(f"film vs oracle: within 1e-3 {(d <= 1e-3).mean():.5f}, outliers {int((d > 1e-3).sum())} of {d.size}, MAE/mean {d.mean():.3g}")
+        assert (d <= 1e-3).mean() >= 0.999 and d.mean() <= 1e-6          # measured: no outlier among 3 072 pixels, MAE 2.3e-7
         # tone-mapped bytes of the device against the oracle's toInt on the same sum, both channel orders
         for rgb in (False, True):
             assert np.array_equal(film.tonemap(4.0, rgb=rgb), ol.tonemap(got, 4.0, rgb=rgb))
         # ... and against the bytes of the oracle's own sum: off by one level at most, on few pixels
         diff = np.abs(film.tonemap(4.0).astype(int) - ol.tonemap(oracle_sum, 4.0).astype(int))
-        assert diff.max() <= 1 or (diff > 1).mean() < 0.03
+        print(f"tone-mapped bytes vs the oracle's: differ on {(diff > 0).mean():.5f}, by more than one level on {(diff > 1).mean():.5f}, max {diff.max()}")
+        assert diff.max() <= 1 and (diff > 0).mean() <= 0.001                # measured: every byte equal
         film.clear()
         assert not film.read().any()
     finally:

@@ -223,10 +223,13 @@ def test_bezier_nearest_hit_over_many_patches(gpu):
     bez = c["obj"] >= 8
     assert bez.sum() > 5000
     same = g["obj"] == c["obj"]
-    assert same[bez].mean() >= 0.99 and same[~bez].mean() >= 0.995      # silhouette rays may converge in one arithmetic only
+    assert same[bez].mean() >= 0.999 and same[~bez].mean() >= 0.9995    # silhouette rays may converge in one arithmetic only (measured: none does)
     both = bez & same
     derr = np.abs(g["dist"][both] - c["dist"][both])
-    assert np.median(derr) < 1e-4 and (derr < 1e-3).mean() >= 0.97 and derr.max() < 0.05
+    print(f"same object: Bezier {same[bez].mean():.5f} of {int(bez.sum())}, others {same[~bez].mean():.5f}; dist median {np.median(derr):.2e}, "
+          f"within 1e-3 {(derr < 1e-3).mean():.5f}, max {derr.max():.2e}")
+    # measured: median 1.5e-6 / 5.5e-7, 99.88 / 99.90 % within 1e-3, worst 9.1e-3 / 7.8e-3 (the residual rule's 0.01)
+    assert np.median(derr) < 5e-6 and (derr < 1e-3).mean() >= 0.9975 and derr.max() < 0.02
 
 
 def test_axis_parallel_rays_through_the_teapot(gpu):
@@ -250,10 +253,13 @@ def test_axis_parallel_rays_through_the_teapot(gpu):
     bez = c["obj"] >= 8
     assert bez.sum() > 3000
     same = g["obj"] == c["obj"]
-    assert same[bez].mean() >= 0.99 and same[~bez].mean() >= 0.99
+    assert same[bez].mean() >= 0.999 and same[~bez].mean() >= 0.9995    # measured: every ray
     both = bez & same
     derr = np.abs(g["dist"][both] - c["dist"][both])
-    assert np.median(derr) < 1e-4 and (derr < 1e-3).mean() >= 0.97 and derr.max() < 0.05
+    print(f"same object: Bezier {same[bez].mean():.5f} of {int(bez.sum())}, others {same[~bez].mean():.5f}; dist median {np.median(derr):.2e}, "
+          f"within 1e-3 {(derr < 1e-3).mean():.5f}, max {derr.max():.2e}")
+    # measured: median 1.5e-6 / 5.5e-7, 99.88 / 99.90 % within 1e-3, worst 9.1e-3 / 7.8e-3 (the residual rule's 0.01)
+    assert np.median(derr) < 5e-6 and (derr < 1e-3).mean() >= 0.9975 and derr.max() < 0.02
 
 
 def _tilted_square(lo, size):
@@ -702,3 +708,41 @@ def test_single_photons_between_passes_leave_the_next_pass_alone(gpu):
     assert np.array_equal(_key(got), _key(want)) and np.array_equal(got["newN"], want["newN"]) and want["newN"].sum() > 10000
     assert np.allclose(got["tao"], want["tao"], rtol=2e-4, atol=1e-6 * want["tao"].mean())
     assert all(c_got[k] == c_want[k] for k in ("segments", "deposits", "candidates", "accepted")), (c_got, c_want)
+
+
+def test_view_trace_as_the_first_call_of_a_context_with_a_two_lobe_material():
+    """sppm_view_trace on a context that has run no eye pass yet, in a scene whose glass both reflects and refracts: the
+    branch queue such a scene needs (65 536 records at least) is larger than the seed queue of a few thousand rays, and
+    the queues have to reach that size before the caller's rays are copied in, not after.  The camera's own rays through
+    it give the oracle's eye-pass HitPoints: same (pixel, tree node) set with branches, same objects, positions and weights."""
+    from raytrace3_amd import SppmContext
+    s = scenes.FlatScene()
+    s.add_plane((50, 0, 81.6), (0, -1, 0), (.75, .75, .75), scenes.WHITE_DIFF)
+    s.add_plane((50, 40.8, 0), (0, 0, 1), (.75, .75, .75), scenes.MIRROR)
+    s.add_sphere(14, (30, 14, 70), (.999, .999, .999), scenes.material(refl=(.3, .3, .3), refr=(.6, .6, .6), refrn=1.5))
+    s.add_sphere(8, (60, 8, 100), (.9, .5, .5), scenes.WHITE_DIFF)
+    s.add_light((50, 60, 85), (5000, 5000, 5000))
+    cam = scenes.default_camera(80, 60)
+    lib = ol.load()
+    org, d, pix = np.zeros((cam.w * cam.h, 3)), np.zeros((cam.w * cam.h, 3)), np.arange(cam.w * cam.h)
+    for p in pix:
+        lib.oracle_camera_emit(cam, int(p) // cam.w, int(p) % cam.w, ol.dp(org[p]), ol.dp(d[p]))
+    o = _oracle(s)
+    o.eye_pass(cam, SEED, 2)
+    want = o.hitpoints()
+    want = want[np.argsort(_key(want))]
+    assert (want["node"] > 2).any() and len(want) > 1.05 * len(np.unique(want["x"] * 4096 + want["y"]))      # the tree branched
+    fresh = SppmContext(0)
+    try:
+        fresh.set_scene(s)
+        got = fresh.view_trace(org, d, np.ones((len(pix), 3)), pix, cam.w, SEED, 2)
+        again = fresh.view_trace(org[:1000], d[:1000], np.ones((1000, 3)), pix[:1000], cam.w, SEED, 2)
+    finally:
+        fresh.close()
+    got = got[np.argsort(_key(got))]
+    assert np.array_equal(_key(got), _key(want)) and np.array_equal(got["obj"], want["obj"])
+    assert np.allclose(got["pos"], want["pos"], rtol=1e-10, atol=1e-7)
+    assert np.allclose(got["wgt"], want["wgt"], rtol=2e-5, atol=1e-7)
+    again = again[np.argsort(_key(again))]
+    sel = np.isin(_key(got), _key(again))
+    assert sel.sum() == len(again) > 0 and np.array_equal(got["pos"][sel], again["pos"])

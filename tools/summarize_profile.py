@@ -66,9 +66,25 @@ def main():
         if "SQ_BUSY_CYCLES" in d and d.get("SQ_ACTIVE_INST_VALU"):
             d["valu_active_per_wave_cycle"] = d["SQ_ACTIVE_INST_VALU"] / max(1.0, d.get("SQ_WAVE_CYCLES", 0.0))
     out = {k: v for k, v in out.items() if k.startswith("k_")}
+    # the kernel sources these counters were collected from (bench.py compares: `counters_stale`)
+    # The stamp is the one the profiled run printed itself; a run from before bench.py printed it is stamped with the sources
+    # as they are now.
+    stamp = None
+    try:
+        with open(bj) as f:
+            stamp = json.loads(f.read().strip().splitlines()[-1]).get("kernel_source_sha256")
+    except (OSError, ValueError, IndexError):
+        pass
+    if not stamp:
+        sys.path.insert(0, ROOT)
+        from bench import kernel_source_sha256
+        stamp = kernel_source_sha256()
+    out["_meta"] = {"kernel_source_sha256": stamp}
     with open(os.path.join(dst, f"{name}_pmc.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     for k, d in sorted(out.items()):
+        if k == "_meta":
+            continue
         print(k, {a: (round(b, 1) if isinstance(b, float) else b) for a, b in d.items() if a != "launches_per_pass"})
 
 
