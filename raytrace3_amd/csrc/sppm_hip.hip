@@ -226,8 +226,9 @@ enum { MODE_EYE = 0, MODE_PHOTON = 1 };
 #define TRACE_SLOT_CHUNK 256u
 #endif
 #define TRACE_LDS_LIGHTS 16        // lights kept in LDS by the photon kernel (40 bytes each); more are read from global memory
-// what the photon kernel keeps in LDS beside the scene tables: 4 waves x 128 emission directions, the first lights, the sine table
-#define TRACE_PHOTON_LDS_EXTRA (4 * 128 * 3 * sizeof(double) + TRACE_LDS_LIGHTS * sizeof(DevLight) + 2 * SPPM_SINCOS_TAB * sizeof(double))
+// what the photon kernel keeps in LDS beside the scene tables: 128 emission directions per wave, the first lights, the sine table
+#define TRACE_PHOTON_LDS(waves) ((waves) * 128 * 3 * sizeof(double) + TRACE_LDS_LIGHTS * sizeof(DevLight) + 2 * SPPM_SINCOS_TAB * sizeof(double))
+#define TRACE_PHOTON_LDS_EXTRA TRACE_PHOTON_LDS(4)
 #define DEP_HOLE 0x00ffffffu      // DepB::bucket of a claimed but unused slot (buckets are < 2^22)
 
 struct TraceParams {
@@ -290,6 +291,9 @@ __device__ __forceinline__ void trace_body(const SceneParams& sp, const TracePar
     // the host sizes a resume launch without knowing its count: workgroups beyond the work leave at once
     if (blockIdx.x > 0 && (unsigned long long)blockIdx.x * blockDim.x >= total) return;
     SceneView S = stage_scene<IN_LDS>(sp);
+#ifdef TRACE_SETPRIO
+    __builtin_amdgcn_s_setprio(TRACE_SETPRIO);   // experiment: the trace wave's issue priority over the gather waves that share its SIMD
+#endif
     const int lane = lane_id();
     bool active = false, pending = false, exhausted = (total == 0);
     d3 o = mk(0, 0, 0), d = mk(0, 0, 1);
@@ -307,7 +311,7 @@ __device__ __forceinline__ void trace_body(const SceneParams& sp, const TracePar
     double* emit_dir = (double*)((char*)lds_scene + (IN_LDS ? ((sp.blob_bytes + 15) & ~15) : 0)) + (threadIdx.x >> 6) * (3 * 128);
     // Up to TRACE_LDS_LIGHTS lights are copied behind the emission slices: a refill then reads its light from LDS instead of
     // waiting for a vector load from global memory at the head of a turn of the loop.
-    DevLight* lds_lights = (DevLight*)((double*)((char*)lds_scene + (IN_LDS ? ((sp.blob_bytes + 15) & ~15) : 0)) + 4 * (3 * 128));
+    DevLight* lds_lights = (DevLight*)((double*)((char*)lds_scene + (IN_LDS ? ((sp.blob_bytes + 15) & ~15) : 0)) + (blockDim.x >> 6) * (3 * 128));
     const bool lights_in_lds = MODE == MODE_PHOTON && tp.n_lights <= TRACE_LDS_LIGHTS;
     // and behind the lights the table of sincos_2pi_u24 (the diffuse bounce's angle about the normal)
     double* lds_sincos = (double*)(lds_lights + TRACE_LDS_LIGHTS);
@@ -1512,6 +1516,7 @@ struct sppm_ctx {
     // together, and a trace kernel of one context then runs beside the gather of another instead of after it.
     int gather_blocks_per_cu = 0;
     int trace_blocks_per_cu = 0;
+    int trace_wg_threads = 256;           // threads of a trace workgroup (SPPM_TRACE_WG: 64, 128 or 256)
     int eye_blocks_per_cu = 0;            // the eye pass's own value of trace_blocks_per_cu (0: the same rule)
     int scatter_blocks_per_cu = 32;
     bool verbose = false;
@@ -1687,6 +1692,7 @@ int sppm_create(sppm_ctx** out, int device_id) {
     if (const char* b = getenv("SPPM_SCATTER_BPC")) ctx->scatter_blocks_per_cu = std::max(1, atoi(b));
     if (const char* b = getenv("SPPM_TRACE_BPC")) ctx->trace_blocks_per_cu = std::max(0, atoi(b));
     if (const char* b = getenv("SPPM_EYE_BPC")) ctx->eye_blocks_per_cu = std::max(0, atoi(b));
+    if (const char* b = getenv("SPPM_TRACE_WG")) { const int t = atoi(b); if (t == 64 || t == 128 || t == 256) ctx->trace_wg_threads = t; }
     if (const char* b = getenv("SPPM_NEWTON_BPC")) ctx->newton_blocks_per_cu = std::max(1, atoi(b));
     if (const char* b = getenv("SPPM_DEP_FILTER")) ctx->dep_filter = atoi(b) != 0;
     if (const char* b = getenv("SPPM_PLACE")) ctx->place_enabled = atoi(b) != 0;
@@ -2062,13 +2068,18 @@ static int close_chunks(sppm_ctx* ctx, Deposit* dep, RawHit* hits, uint64_t cap)
 template <int MODE>
 static void launch_trace(sppm_ctx* ctx, bool coop, int blocks, const SceneParams& sp, const TraceParams& tp) {
     // dynamic LDS: the scene tables, then (photon pass) 4 waves x 128 emission directions, the first lights and the sine table
-    const size_t lds = (ctx->scene_in_lds ? (((size_t)ctx->blob_bytes + 15) & ~(size_t)15) : 0) + (MODE == MODE_PHOTON ? TRACE_PHOTON_LDS_EXTRA : 0);
-    if (!ctx->scene_in_lds) hipLaunchKernelGGL((k_trace<MODE, true, false>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);   // coop_only
-    else if (coop && sp.n_patches == 0 && MODE == MODE_PHOTON) hipLaunchKernelGGL(k_trace_photon_plain, dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
-    else if (coop && sp.n_patches == 0) hipLaunchKernelGGL((k_trace<MODE, true, true, false>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
-    else if (coop && MODE == MODE_PHOTON) hipLaunchKernelGGL(k_trace_photon_bez, dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
-    else if (coop) hipLaunchKernelGGL(k_trace_eye_bez, dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
-    else hipLaunchKernelGGL((k_trace<MODE, false, true>), dim3(blocks), dim3(256), lds, ctx->stream, sp, tp);
+    // A trace workgroup is four waves unless SPPM_TRACE_WG says otherwise (64 or 128 threads: a workgroup's registers and LDS
+    // are given back when its LAST wave is done, so smaller workgroups free a SIMD's slot for another context's kernel sooner
+    // at the end of a launch; the grid has as many waves either way).
+    const int threads = ctx->trace_wg_threads;
+    blocks *= 256 / threads;
+    const size_t lds = (ctx->scene_in_lds ? (((size_t)ctx->blob_bytes + 15) & ~(size_t)15) : 0) + (MODE == MODE_PHOTON ? TRACE_PHOTON_LDS(threads / 64) : 0);
+    if (!ctx->scene_in_lds) hipLaunchKernelGGL((k_trace<MODE, true, false>), dim3(blocks), dim3(threads), lds, ctx->stream, sp, tp);   // coop_only
+    else if (coop && sp.n_patches == 0 && MODE == MODE_PHOTON) hipLaunchKernelGGL(k_trace_photon_plain, dim3(blocks), dim3(threads), lds, ctx->stream, sp, tp);
+    else if (coop && sp.n_patches == 0) hipLaunchKernelGGL((k_trace<MODE, true, true, false>), dim3(blocks), dim3(threads), lds, ctx->stream, sp, tp);
+    else if (coop && MODE == MODE_PHOTON) hipLaunchKernelGGL(k_trace_photon_bez, dim3(blocks), dim3(threads), lds, ctx->stream, sp, tp);
+    else if (coop) hipLaunchKernelGGL(k_trace_eye_bez, dim3(blocks), dim3(threads), lds, ctx->stream, sp, tp);
+    else hipLaunchKernelGGL((k_trace<MODE, false, true>), dim3(blocks), dim3(threads), lds, ctx->stream, sp, tp);
 }
 static int launch_trace_mode(sppm_ctx* ctx, int mode, bool coop, int blocks, const TraceParams& tp) {
     const SceneParams sp = ctx->scene_params();
