@@ -416,6 +416,11 @@ struct oracle_ctx {
     // instead of 0, and the sweep of Raytracer.h:237-245 runs after every rounds_per_update rounds.
     int initial_n = 0;
     uint32_t rounds_per_update = 1;
+    // A measuring switch, not the reference's arithmetic: every ray direction and every hit normal is rounded to float
+    // before it is used (positions, distances and the 1e-4 guards stay double).  It answers what a device path that kept
+    // directions and normals in float would do to HitPoints, tallies and the image (tests/report_narrow_ray_bias.py).
+    bool narrow_rays = false;
+    V3 narrow(const V3& v) const { return narrow_rays ? V3((double)(float)v.x, (double)(float)v.y, (double)(float)v.z) : v; }
     // exact uniform grid over HitPoints
     std::unordered_map<uint64_t, std::vector<int>> grid;
     // kd-tree
@@ -555,11 +560,13 @@ struct oracle_ctx {
     }
 
     // ---- Raytracer.h:296-357 ViewTrace (recursive tree)
-    void ViewTrace(const V3& org, const V3& dir, int dep, V3 wgt, int x, int y, uint32_t node,
+    void ViewTrace(const V3& org, const V3& dir_in, int dep, V3 wgt, int x, int y, uint32_t node,
                    uint64_t seed, uint32_t replica) {
+        const V3 dir = narrow(dir_in);
         if (dep <= MAX_DEP_) cnt.eye_segments++;   // like `segments`: the call whose result the depth test discards is not tallied
         Rand rnd = make_rand(seed, replica, D_EYE, (uint32_t)(x * cam.w + y), node);
         Collision c1 = NearCollide(org, dir, rnd);
+        c1.N = narrow(c1.N);
         if (!c1.IsValid()) return;
         if (dep > MAX_DEP_) return;
         dep++;
@@ -679,7 +686,9 @@ struct oracle_ctx {
         for (;;) {
             Rand rnd = make_rand(seed, replica, D_PHOTON, photon, (uint32_t)dep);
             if (dep <= MAX_DEP_) cnt.segments++;
+            dir = narrow(dir);
             Collision c1 = NearCollide(org, dir, rnd);
+            c1.N = narrow(c1.N);
             if (!c1.IsValid()) return;
             if (dep > MAX_DEP_) return;
             int vertex = dep;
@@ -749,6 +758,12 @@ int oracle_set_radius_update(oracle_ctx* ctx, int32_t initial_n, uint32_t rounds
     if (!ctx || initial_n < 0 || (initial_n > 0 && rounds_per_update == 0)) return SPPM_E_INVALID;
     ctx->initial_n = initial_n;
     ctx->rounds_per_update = rounds_per_update ? rounds_per_update : 1;
+    return SPPM_OK;
+}
+
+int oracle_set_narrow_rays(oracle_ctx* ctx, int on) {
+    if (!ctx) return SPPM_E_INVALID;
+    ctx->narrow_rays = on != 0;
     return SPPM_OK;
 }
 

@@ -34,6 +34,10 @@ void oracle_destroy(oracle_ctx* ctx);
 /* The radius-update knob of sppm_set_radius_update restated (initial_n = 0: the reference's dead update()). */
 int oracle_set_radius_update(oracle_ctx* ctx, int32_t initial_n, uint32_t rounds_per_update);
 
+/* A measuring switch (not the reference's arithmetic): ray directions and hit normals rounded to float before use,
+ * everything else as it is.  Off by default. */
+int oracle_set_narrow_rays(oracle_ctx* ctx, int on);
+
 int oracle_set_scene(oracle_ctx* ctx, const sppm_scene* scene);
 int oracle_eye_pass(oracle_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t replica);
 /* The rows [row_begin, row_end) of GetHitPoint's outer loop (Raytracer.h:105): with counter-based streams a pixel's

@@ -824,8 +824,10 @@ static_assert(sizeof(HpRec) == 64, "one memory line per HitPoint");
 // partly filled memory line per HitPoint.  Only the record the gather reads goes this way, as one line; the fields every HitPoint starts with alike (R2, tao, newN) are filled in order by k_hp_occupancy, and the
 // ones only a host that asks for the HitPoints (or the radius update) reads are written by k_hp_meta when asked for, through
 // the place noted here in the order of the raw array.
+// n_hp: the HitPoint count the sorted arrays were sized for (the eye kernel's tally).  A record whose place lies beyond it
+// would mean that tally and the histogram disagree: it is not written, and the pass reports a device error.
 __global__ void k_hp_scatter(const RawHit* hits, uint32_t n, GridParams g, const uint32_t* start,
-                             uint32_t* cursor, HpRec* hp, uint32_t* sorted_of_raw) {
+                             uint32_t* cursor, HpRec* hp, uint32_t* sorted_of_raw, uint32_t n_hp, unsigned int* overflow) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const RawHit h = hits[i];
@@ -833,6 +835,7 @@ __global__ void k_hp_scatter(const RawHit* hits, uint32_t n, GridParams g, const
     PosKey pk; pk.x = h.pos[0]; pk.y = h.pos[1]; pk.z = h.pos[2]; pk.key = cell_key(ld3(h.pos), g.inv_cs);
     const uint32_t b = key_bucket(pk.key, g.mask);
     uint32_t s = start[b] + atomicAdd(&cursor[b], 1u);
+    if (s >= n_hp) { atomicOr(overflow, 16u); sorted_of_raw[i] = 0xffffffffu; return; }
     HpRec r;
     r.a = pk;
     r.nr = make_float4(h.n[0], h.n[1], h.n[2], 0.f);
@@ -1517,6 +1520,7 @@ struct sppm_ctx {
     int gather_blocks_per_cu = 0;
     int trace_blocks_per_cu = 0;
     int trace_wg_threads = 256;           // threads of a trace workgroup (SPPM_TRACE_WG: 64, 128 or 256)
+    int eye_blocks = 0;                   // at most so many workgroups for the eye trace (SPPM_EYE_BLOCKS; 0: by the per-CU rule)
     int eye_blocks_per_cu = 0;            // the eye pass's own value of trace_blocks_per_cu (0: the same rule)
     int scatter_blocks_per_cu = 32;
     bool verbose = false;
@@ -1692,6 +1696,7 @@ int sppm_create(sppm_ctx** out, int device_id) {
     if (const char* b = getenv("SPPM_SCATTER_BPC")) ctx->scatter_blocks_per_cu = std::max(1, atoi(b));
     if (const char* b = getenv("SPPM_TRACE_BPC")) ctx->trace_blocks_per_cu = std::max(0, atoi(b));
     if (const char* b = getenv("SPPM_EYE_BPC")) ctx->eye_blocks_per_cu = std::max(0, atoi(b));
+    if (const char* b = getenv("SPPM_EYE_BLOCKS")) ctx->eye_blocks = std::max(0, atoi(b));
     if (const char* b = getenv("SPPM_TRACE_WG")) { const int t = atoi(b); if (t == 64 || t == 128 || t == 256) ctx->trace_wg_threads = t; }
     if (const char* b = getenv("SPPM_NEWTON_BPC")) ctx->newton_blocks_per_cu = std::max(1, atoi(b));
     if (const char* b = getenv("SPPM_DEP_FILTER")) ctx->dep_filter = atoi(b) != 0;
@@ -2128,7 +2133,8 @@ static int read_queues(sppm_ctx* ctx, QueueState& q) {
 #define SPPM_RETRY_HITS (SPPM_E_CAPACITY + 100)
 #define SPPM_RETRY_PARK (SPPM_E_CAPACITY + 101)
 #define SPPM_RETRY_DEP (SPPM_E_CAPACITY + 102)
-// Overflow bits: 1 HitPoint buffer, 2 ray / task queue, 4 deposit buffer or overflow list, 8 gather piece queue.  A pass whose
+// Overflow bits: 1 HitPoint buffer, 2 ray / task queue, 4 deposit buffer or overflow list, 8 gather piece queue, 16 a HitPoint
+// placed beyond the sorted arrays (k_hp_scatter: never expected).  A pass whose
 // host is still there to run it again (the eye pass; a counting-sorted photon batch) retries with more room, told which by
 // the RETRY codes; everything else is an error.
 static int overflow_code(sppm_ctx* ctx, const DevCounters& dc, bool can_retry_queues = false) {
@@ -2142,6 +2148,7 @@ static int overflow_code(sppm_ctx* ctx, const DevCounters& dc, bool can_retry_qu
         ctx->dep_per_photon = SPPM_MAX_DEP + 1;
         ctx->place_valid = false;
     }
+    if (dc.overflow & 16u) return fail(ctx, SPPM_E_DEVICE, "the HitPoint tally and the HitPoint histogram of an eye pass disagree");
     if (dc.overflow & 14u) return fail(ctx, SPPM_E_CAPACITY, "a ray / task / deposit / gather-piece queue overflowed");
     return SPPM_RETRY_HITS;   // HitPoint buffer too small: the eye pass retries with more room
 }
@@ -2230,6 +2237,7 @@ static int run_trace(sppm_ctx* ctx, int mode, TraceParams tp, uint64_t fresh_fir
     const bool legacy = (mode == MODE_PHOTON && !first_coop);   // photons with parked solves: every round looks at the counters
     if (int rc = set_round(n_seed > 0 ? 1 : 0, n_seed == 0)) return rc;       // seeds: read queue 1, write queue 0
     int first_blocks = blocks_for(n_seed > 0 ? n_seed : fresh_count, first_coop);
+    if (mode == MODE_EYE && ctx->eye_blocks > 0) first_blocks = std::max(1, std::min(first_blocks, ctx->eye_blocks));
     if (int rc = launch_trace_mode(ctx, mode, first_coop, first_blocks, tp)) return rc;
     int cur = 0;   // queue written by the last launch
     if (!legacy) {
@@ -2350,7 +2358,7 @@ int sppm_eye_pass(sppm_ctx* ctx, const sppm_camera* cam, uint64_t seed, uint32_t
         if (int rc = launch_scan(ctx, ctx->hcount(), ctx->hstart.p, M, nullptr, ctx->raw.p, hit_cap)) return rc;   // + chunk tails -> holes
         HIPCHK(ctx->sorted_of_raw.reserve(std::max<uint64_t>(hit_cap, 1)));   // as many as the raw array holds: the claimed count wanders with the jitter, and growing a buffer waits for the GPU
         hipLaunchKernelGGL(k_hp_scatter, dim3(blocks), dim3(256), 0, ctx->stream, ctx->raw.p, (uint32_t)claimed, ctx->grid,
-                           ctx->hstart.p, ctx->cursor(), ctx->hp_rec.p, ctx->sorted_of_raw.p);
+                           ctx->hstart.p, ctx->cursor(), ctx->hp_rec.p, ctx->sorted_of_raw.p, (uint32_t)n, &ctx->counters.p->overflow);
         hipLaunchKernelGGL(k_hp_occupancy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->hp_rec.p, (uint32_t)n, ctx->grid, ctx->occ(),
                            ctx->hp_r2.p, ctx->hp_tao.p);
         HIPCHK(hipGetLastError());

@@ -22,6 +22,7 @@ SYMBOLS = {
     "oracle_create": (C.c_void_p, [C.c_int, C.c_int]),
     "oracle_destroy": (None, [C.c_void_p]),
     "oracle_set_radius_update": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint32]),
+    "oracle_set_narrow_rays": (C.c_int, [C.c_void_p, C.c_int]),
     "oracle_set_scene": (C.c_int, [C.c_void_p, C.POINTER(abi.Scene)]),
     "oracle_eye_pass": (C.c_int, [C.c_void_p, C.POINTER(abi.Camera), C.c_uint64, C.c_uint32]),
     "oracle_eye_pass_rows": (C.c_int, [C.c_void_p, C.POINTER(abi.Camera), C.c_uint64, C.c_uint32, C.c_int, C.c_int]),
@@ -91,6 +92,9 @@ class OracleContext:
 
     def set_radius_update(self, initial_n, rounds_per_update=1):
         assert self.lib.oracle_set_radius_update(self._ctx, int(initial_n), int(rounds_per_update)) == 0
+
+    def set_narrow_rays(self, on):
+        assert self.lib.oracle_set_narrow_rays(self._ctx, int(bool(on))) == 0
 
     def set_scene(self, scene):
         self._keep = scene
@@ -179,6 +183,10 @@ class ParallelOracle:
     def set_scene(self, scene):
         for p in self.parts:
             p.set_scene(scene)
+
+    def set_narrow_rays(self, on):
+        for p in self.parts:
+            p.set_narrow_rays(on)
 
     def _run(self, jobs, fn):
         """jobs are dealt to the worker contexts from one list, so an uneven job (rows that cross a teapot) does not

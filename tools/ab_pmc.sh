@@ -7,7 +7,7 @@ cd "$REPO"; export TMPDIR=/tmp
 for L in "$@"; do
   TAG=$(basename "$L" .so); OUT=$REPO/gpurun_out/abpmc_$TAG; rm -rf "$OUT"; mkdir -p "$OUT"
   export SPPM_LIB_PATH=$REPO/$L
-  timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU --output-format csv -d "$OUT" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "pmc pass failed for $L"; tail -5 "$OUT/bench.err"; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU --output-format csv -d "$OUT" -- python3 bench.py --steps 2 --warmup 1 --steady-steps 0 --no-cpu-baseline --inflight 1 > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "pmc pass failed for $L"; tail -5 "$OUT/bench.err"; exit 1; }
   python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, sys, collections
 out, tag = sys.argv[1], sys.argv[2]

@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$REPO"
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 3 --warmup 1 --steady-steps 0 --no-cpu-baseline $*"
 echo "== stats"; 
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py $ARGS > "$OUT/bench_stats.json" 2> "$OUT/bench_stats.err" || { echo "stats pass failed"; tail -5 "$OUT/bench_stats.err"; exit 1; }
 echo "== pmc FETCH_SIZE"
