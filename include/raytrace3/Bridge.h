@@ -65,7 +65,7 @@ struct Device {
         check(sppm_set_scene(ctx, &scene), "sppm_set_scene");
         scene_tag = tag;
     }
-    // Flattens the live objects and lights (Scene.h defines it, after the classes it reads) and calls use_scene.
+    // Flattens the live objects and lights (defined at the end of Obj.h, after the classes it reads) and calls use_scene.
     void ensure_scene(const std::vector<Obj*>& objvec, const std::vector<Light*>& plvec);
     static Device& get(int slot_index) {
         static std::mutex reg_mu;
