@@ -582,6 +582,7 @@ __device__ __forceinline__ void trace_body(const SceneParams& sp, const TracePar
             }
         } else {
             bool dp = false, keep = false;
+            uint32_t pbase = 0, pend = 0, prank = 0, pocc = 0;
             PosKey da;
             DepB db;
             if (active) {
@@ -597,8 +598,20 @@ __device__ __forceinline__ void trace_body(const SceneParams& sp, const TracePar
                     const uint32_t bk = key_bucket(da.key, tp.grid.mask);
                     db.bucket = bk | (vertex << 24); db.photon = id;
                     if (tp.dcount_all) atomicAdd(&tp.dcount_all[bk], 1u);
-                    // no HitPoint in the 27 cells around: the gather would never look at this deposit
-                    keep = !tp.occ || tp.occ[bk] != 0;
+                    if (tp.place) {
+                        // A placed deposit asks for everything its store will need right here, in one go and before the bounce
+                        // is worked out: the occupancy byte, the bucket's room and — the returned atomic — its rank in the
+                        // bucket.  The answers are looked at where the record is stored (the asm statement below keeps the
+                        // compiler from waiting for them any earlier).  The rank is asked for before the occupancy byte is
+                        // known, so the fill count of a bucket out of every HitPoint's reach also counts the deposits that
+                        // are then dropped: nobody reads that count (the gather only visits buckets within reach).
+                        pbase = tp.place[bk]; pend = tp.place[bk + 1];
+                        pocc = tp.occ ? (uint32_t)tp.occ[bk] : 1u;
+                        prank = atomicAdd(&tp.dcount[bk], 1u);
+                    } else {
+                        // no HitPoint in the 27 cells around: the gather would never look at this deposit
+                        keep = !tp.occ || tp.occ[bk] != 0;
+                    }
                 }
                 // Obj::Roulette, Obj.h:30-45
                 // A material with one lobe (every one of the reference's scene) has one outcome whatever r is: the draw, which
@@ -629,13 +642,15 @@ __device__ __forceinline__ void trace_body(const SceneParams& sp, const TracePar
             }
             STAMP(6);
             ndep += count_lanes(dp);
+            if (tp.place) {
+                asm volatile("" : "+v"(pocc), "+v"(pbase), "+v"(pend), "+v"(prank));     // the answers: not before this point
+                keep = pocc != 0;
+            }
             dp = dp && keep;
             nstored += count_lanes(dp);
             if (tp.place) {
                 if (dp) {
-                    const uint32_t bk = db.bucket & 0xffffffu;
-                    const uint32_t base = tp.place[bk], room = tp.place[bk + 1] - base;
-                    const uint32_t rank = atomicAdd(&tp.dcount[bk], 1u);
+                    const uint32_t base = pbase, room = pend - pbase, rank = prank;
                     Deposit rec; rec.a = da; rec.b = db;
                     if (rank < room) {
                         tp.sorted[base + rank] = rec;
@@ -682,12 +697,12 @@ __global__ void __launch_bounds__(256, COOP ? (MODE == MODE_EYE ? TRACE_EYE_OCC 
     trace_body<MODE, COOP, IN_LDS, BEZ>(sp, tp);
 }
 // The two kernels the reference's scene runs, under names of their own so that each can be held to a register count
-// (the attribute counts register PAIRS of the unified file here: 116 means 232 VGPRs).  Left alone the photon kernel takes
+// (the attribute counts register PAIRS of the unified file here: 104 means 208 VGPRs).  Left alone the photon kernel takes
 // 244, i.e. 248 allocated: beside three gather workgroups of 80 that leaves 24 registers per lane of a SIMD, and the small
 // kernels between the passes (scans, HitPoint scatter, occupancy, resolve: 32 to 40 registers) wait for a workgroup to
-// leave.  At 232 nothing spills and they fit in.
+// leave.  At 232 nothing spills and they fit in; at 208 twenty values spill, the kernel takes the same time and leaves 64.
 #ifndef TRACE_PHOTON_VGPRS
-#define TRACE_PHOTON_VGPRS 116
+#define TRACE_PHOTON_VGPRS 104
 #endif
 #ifndef TRACE_EYE_VGPRS
 #define TRACE_EYE_VGPRS 0
