@@ -1032,9 +1032,11 @@ __device__ __forceinline__ void gather_tile(const uint32_t base, const HpRec* __
             const int dx = lane % 3 - 1, dy = (lane / 3) % 3 - 1, dz = lane / 9 - 1;
             nb_key = key + ((uint64_t)(int64_t)dx << 42) + ((uint64_t)(int64_t)dy << 21) + (uint64_t)(int64_t)dz;
             const uint32_t b = key_bucket(nb_key, g.mask);
-            nb_s = dstart[b];
-            nb_len = dstart[b + 1] - nb_s;
-            if (dlen) nb_len = min(nb_len, dlen[b]);   // directly placed deposits: the bucket's room is only partly filled
+            // three loads asked for together, one wait: the bucket's room and how much of it is filled (directly placed deposits
+            // fill their bucket's room only partly; after a counting sort the fill count IS the room)
+            const uint32_t s0 = dstart[b], s1 = dstart[b + 1], filled = dlen[b];
+            nb_s = s0;
+            nb_len = min(s1 - s0, filled);
         }
         // The non-empty ranges, concatenated, form one flat list; a row is 64 consecutive entries of it
         // (lane l of the row at flat offset F holds entry F + l), so rows are full except the last.
@@ -1191,11 +1193,16 @@ __global__ void __launch_bounds__(256) k_gather(const HpRec* __restrict__ hp,
     for (uint32_t s = 0; s < 8; s++) {
         const uint32_t q = (blockIdx.x + s) & 7u;
         const uint32_t q_end = min(n_tiles, (q + 1) * per);
+        // A wave asks for its next tile before it works on the one it has, so that the counter's answer travels while the
+        // tile's HitPoints are loaded (the asm statement keeps the compiler from waiting for it where it is asked for).  Every
+        // wave thus claims one tile number beyond the eighth's end before it moves on, which nobody minds.
+        uint32_t claimed = 0;
+        if (lane_id() == 0) claimed = atomicAdd(&tile_ctr[q * 16], 1u);
         for (;;) {
-            uint32_t t = 0;
-            if (lane_id() == 0) t = atomicAdd(&tile_ctr[q * 16], 1u);
-            t = bcast_u(t, 0) + q * per;
+            asm volatile("" : "+v"(claimed));
+            const uint32_t t = bcast_u(claimed, 0) + q * per;
             if (t >= q_end) break;
+            if (lane_id() == 0) claimed = atomicAdd(&tile_ctr[q * 16], 1u);
             gather_tile<false, FIXED_R2>(t * GATHER_TILE, hp, hp_r2, hp_tao, n_hp, dstart, dlen, deps, g, pieces, n_pieces, piece_cap,
                                &counters->overflow, GatherPiece{0, 0, 0, 0}, cand, acc_n, row_tests);
         }
@@ -2451,7 +2458,7 @@ int sppm_synchronize(sppm_ctx* ctx) {
     return SPPM_OK;
 }
 
-// k_gather + k_gather_split over the grid-sorted deposits [dstart[b], +dlen[b] or to dstart[b + 1]); `over`: the deposits
+// k_gather + k_gather_split over the grid-sorted deposits [dstart[b], + min(dlen[b], dstart[b + 1] - dstart[b])); `over`: the deposits
 // that found their bucket full under direct placement.  fixed_r2: every radius is still INIT_R2.
 static int launch_gather(sppm_ctx* ctx, const uint32_t* dstart, const uint32_t* dlen, const Deposit* over, uint64_t dep_cap, bool fixed_r2) {
     tic(ctx, PH_GATHER);
@@ -2524,7 +2531,7 @@ int sppm_photon_pass(sppm_ctx* ctx, uint64_t rounds, uint32_t per_round, uint64_
                             count <= ctx->place_photons && ctx->n_hp > 0;
         bool lay_out = false;     // this batch is counting-sorted and leaves a layout behind
         const uint32_t* dstart = placed ? ctx->place_start.p : ctx->dstart.p;
-        const uint32_t* dlen = placed ? ctx->dcount() : nullptr;
+        const uint32_t* dlen = ctx->dcount();      // placed: the buckets' fill counts; counting-sorted: the histogram the ranges were made from
         uint64_t over_cap = 0;
         if (placed) {
             if (int rc = launch_pass_reset(ctx, false, ctx->dcount(), (size_t)M + 1)) return rc;
@@ -3028,7 +3035,7 @@ int sppm_photon_trace(sppm_ctx* ctx, uint64_t n, const double* org, const double
     HIPCHK(hipGetLastError());
     toc(ctx);
     if (ctx->n_hp > 0)
-        if (int rc2 = launch_gather(ctx, ctx->dstart.p, nullptr, nullptr, dep_cap, !ctx->radii_changed)) return rc2;
+        if (int rc2 = launch_gather(ctx, ctx->dstart.p, ctx->dcount(), nullptr, dep_cap, !ctx->radii_changed)) return rc2;
     if (ctx->last_rounds == 0) { ctx->last_rounds = 1; ctx->last_per_round = 1; }     // a resolve with nothing but such photons: tao / (PI R2)
     return SPPM_OK;
 }
