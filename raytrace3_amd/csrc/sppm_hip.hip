@@ -1195,16 +1195,20 @@ __global__ void __launch_bounds__(256) k_gather(const HpRec* __restrict__ hp,
         const uint32_t q_end = min(n_tiles, (q + 1) * per);
         // A wave asks for its next tile before it works on the one it has, so that the counter's answer travels while the
         // tile's HitPoints are loaded (the asm statement keeps the compiler from waiting for it where it is asked for).  Every
-        // wave thus claims one tile number beyond the eighth's end before it moves on, which nobody minds.
+        // wave thus claims one tile number beyond the eighth's end before it moves on, which nobody minds.  Only where every
+        // wave has several tiles to come, though: a tile reserved ahead is a tile another wave cannot take, and with about as
+        // many tiles as waves (a 256 x 256 picture) that leaves a third of the waves idle while the others do two.
+        const bool ahead = n_tiles >= 4u * ((gridDim.x * blockDim.x) >> 6);
         uint32_t claimed = 0;
         if (lane_id() == 0) claimed = atomicAdd(&tile_ctr[q * 16], 1u);
         for (;;) {
             asm volatile("" : "+v"(claimed));
             const uint32_t t = bcast_u(claimed, 0) + q * per;
             if (t >= q_end) break;
-            if (lane_id() == 0) claimed = atomicAdd(&tile_ctr[q * 16], 1u);
+            if (ahead && lane_id() == 0) claimed = atomicAdd(&tile_ctr[q * 16], 1u);
             gather_tile<false, FIXED_R2>(t * GATHER_TILE, hp, hp_r2, hp_tao, n_hp, dstart, dlen, deps, g, pieces, n_pieces, piece_cap,
                                &counters->overflow, GatherPiece{0, 0, 0, 0}, cand, acc_n, row_tests);
+            if (!ahead && lane_id() == 0) claimed = atomicAdd(&tile_ctr[q * 16], 1u);
         }
     }
     if (lane_id() == 0) {
