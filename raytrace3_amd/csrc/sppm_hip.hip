@@ -2467,7 +2467,7 @@ int sppm_synchronize(sppm_ctx* ctx) {
 static int launch_gather(sppm_ctx* ctx, const uint32_t* dstart, const uint32_t* dlen, const Deposit* over, uint64_t dep_cap, bool fixed_r2) {
     tic(ctx, PH_GATHER);
     const uint64_t tiles = (ctx->n_hp + GATHER_TILE - 1) / GATHER_TILE;
-    // beside a trace wave of 232 registers a SIMD has room for three gather waves, beside one of 160 (no Bezier objects) for four
+    // beside a trace wave of 208 (photons) or 256 (eye) registers a SIMD has room for three gather waves, beside one of 160 (no Bezier objects) for four
     const int gather_bpc = ctx->gather_blocks_per_cu > 0 ? ctx->gather_blocks_per_cu : (shares_gpu(ctx->device) ? (ctx->n_patches == 0 ? 4 : 3) : 5);
     const int blocks = (int)std::max<uint64_t>(8, std::min<uint64_t>((uint64_t)ctx->num_cu * gather_bpc, ((tiles + 3) / 4 + 7) / 8 * 8));
     const uint32_t piece_cap = 1u << 20;
